@@ -1,0 +1,171 @@
+"""Independent numpy restatement of the analytic alignment path (vectorised, gather form).
+
+TEST INFRASTRUCTURE ONLY -- PARITY UNPINNED (the reference holds no tests or golden
+vectors; see oracle/phovo_oracle.h).  This twin exists so that the C oracle is checked
+against something written separately from it: it resolves the residual scatter with an
+explicit "largest source index wins" owner map instead of a serial loop, forms
+J^T J / J^T r with numpy reductions and solves the 6x6 system with numpy.linalg.
+tests/golden/make_golden.py runs it to produce the committed fixtures.
+
+Follows phovo/include/CPhotoconsistencyOdometryAnalytic.h:191-367 (per pixel),
+:376-392 (termination), :500-563 (GN loop), CPhotoconsistencyOdometry.h:47-71 (pose).
+"""
+import numpy as np
+
+
+def level_size(w, h, level):
+    f = 1.0 / (1 << level)
+    return int(np.rint(w * f)), int(np.rint(h * f))
+
+
+def resize_level(img, level):
+    """cv::resize by 2^-L from level 0 (INTER_LINEAR; 2x -> area fast path).  Even sizes only."""
+    if level == 0:
+        return img.copy()
+    s = 1 << level
+    h, w = img.shape
+    assert w % s == 0 and h % s == 0, "twin covers the divisible case only"
+    if s == 2:
+        a, b = img[0::2, 0::2], img[0::2, 1::2]
+        c, d = img[1::2, 0::2], img[1::2, 1::2]
+        return (((a + b) + c) + d) * 0.25
+    o = s // 2 - 1
+    a, b = img[o::s, o::s], img[o::s, o + 1::s]
+    c, d = img[o + 1::s, o::s], img[o + 1::s, o + 1::s]
+    return (a * 0.5 + b * 0.5) * 0.5 + (c * 0.5 + d * 0.5) * 0.5
+
+
+def scharr(img, scale):
+    """cv::Scharr dx / dy, reflect-101 border, smoothing kernel scaled."""
+    k3, k10 = 3.0 * scale, 10.0 * scale
+    p = np.pad(img, 1, mode="reflect")
+    left, mid, right = p[:, :-2], p[:, 1:-1], p[:, 2:]
+    tx = right - left                      # rows still padded vertically
+    ty = ((k3 * left) + (k10 * mid)) + (k3 * right)
+    gx = (k10 * tx[1:-1]) + (k3 * (tx[2:] + tx[:-2]))
+    gy = ty[2:] - ty[:-2]
+    return gx, gy
+
+
+def build_pyramids(gray0, depth0, gray1, num_levels, grad_scale):
+    i0 = gray0.astype(np.float64) * (1.0 / 255)
+    i1 = gray1.astype(np.float64) * (1.0 / 255)
+    out = []
+    for l in range(num_levels):
+        a = resize_level(i0, l)
+        d = resize_level(depth0.astype(np.float64), l)
+        b = resize_level(i1, l)
+        gx, gy = scharr(b, grad_scale[l])
+        out.append((a, d, b, gx, gy))
+    return out
+
+
+def c_round(x):
+    """C round(): half away from zero."""
+    return np.sign(x) * np.floor(np.abs(x) + 0.5)
+
+
+def normal_equations(planes, level, K, state, min_depth=0.3, max_depth=5.0):
+    """One pass of ComputeResidualsAndJacobians + J^T r, J^T J, in gather form.
+
+    Returns (g[6], H[6,6], r[N], J[N,6])."""
+    i0, d0, i1, gx1, gy1 = planes
+    H_, W_ = i0.shape
+    n = H_ * W_
+    sf = 1.0 / 2 ** level
+    fx, fy, ox, oy = K[0, 0] * sf, K[1, 1] * sf, K[0, 2] * sf, K[1, 2] * sf
+    ifx, ify = 1.0 / fx, 1.0 / fy
+    x, y, z, yaw, pitch, roll = state
+    sy_, cy_ = np.sin(yaw), np.cos(yaw)
+    sp, cp = np.sin(pitch), np.cos(pitch)
+    sr, cr = np.sin(roll), np.cos(roll)
+    R = np.array([[cy_ * cp, cy_ * sp * sr - sy_ * cr, cy_ * sp * cr + sy_ * sr],
+                  [sy_ * cp, sy_ * sp * sr + cy_ * cr, sy_ * sp * cr - cy_ * sr],
+                  [-sp, cp * sr, cp * cr]])
+    t1, t2, t3 = cp * sr, cp * cr, sp
+    t4 = sr * sy_ + sp * cr * cy_
+    t5 = sp * sr * cy_ - cr * sy_
+    t6 = sp * sr * sy_ + cr * cy_
+    t7 = -sp * sr * sy_ - cr * cy_
+    t8 = sr * cy_ - sp * cr * sy_
+    t9 = sp * cr * sy_ - sr * cy_
+    t10 = cp * sr * cy_
+    t11 = cp * cy_ + x                       # reference transcription bug (:253)
+    t12 = cp * cr * cy_
+    t13, t14, t15 = sp * cy_, cp * sy_, cp * cy_
+    t16, t17 = sp * sr, sp * cr
+    t18, t19, t20 = cp * sr * sy_, cp * cr * sy_, sp * sy_
+    t21 = cr * sy_ - sp * sr * cy_
+    t22, t23, t24 = cp * cr, cp * sr, cp
+
+    cc, rr = np.meshgrid(np.arange(W_, dtype=np.float64), np.arange(H_, dtype=np.float64))
+    pz = d0.reshape(-1)
+    valid = (min_depth < pz) & (pz < max_depth)
+    with np.errstate(all="ignore"):
+        px = (cc.reshape(-1) - ox) * pz * ifx
+        py = (rr.reshape(-1) - oy) * pz * ify
+        X = R[0, 0] * px + R[0, 1] * py + R[0, 2] * pz + x
+        Y = R[1, 0] * px + R[1, 1] * py + R[1, 2] * pz + y
+        Z = R[2, 0] * px + R[2, 1] * py + R[2, 2] * pz + z
+        iz = 1.0 / Z
+        tc = (X * fx) * iz + ox
+        tr = (Y * fy) * iz + oy
+        tri, tci = c_round(tr), c_round(tc)
+        inb = valid & np.isfinite(tri) & np.isfinite(tci) & \
+            (tri >= 0) & (tri < H_) & (tci >= 0) & (tci < W_)
+        t25 = 1.0 / (z + py * t1 + pz * t2 - px * t3)
+        t26 = t25 * t25
+        A = pz * t4 + py * t5 + px * t11
+        B = py * t6 + pz * t9 + px * t14 + y
+        Cc = -py * t16 - pz * t17 - px * t24
+        D = py * t22 - pz * t23
+        zero = np.zeros(n)
+        Ju = [fx * t25, zero, -fx * A * t26,
+              fx * (py * t7 + pz * t8 - px * t14) * t25,
+              fx * (py * t10 + pz * t12 - px * t13) * t25 - fx * Cc * A * t26,
+              fx * (py * t4 + pz * t21) * t25 - fx * D * A * t26]
+        Jv = [zero, fy * t25, -fy * B * t26,
+              fy * (pz * t4 + py * t5 + px * t15) * t25,
+              fy * (py * t18 + pz * t19 - px * t20) * t25 - fy * Cc * B * t26,
+              fy * (pz * t7 + py * t9) * t25 - fy * D * B * t26]
+        gxi, gyi = gx1.reshape(-1), gy1.reshape(-1)        # gradient at the SOURCE index (:346-347)
+        J = np.stack([gxi * Ju[j] + gyi * Jv[j] for j in range(6)], axis=1)
+    J[~inb] = 0.0
+
+    # scatter r[W*tri+tci] = I1(tri,tci) - I0(i), later source pixels win (:358)
+    src = np.nonzero(inb)[0]
+    tgt = (tri[src] * W_ + tci[src]).astype(np.int64)
+    owner = np.full(n, -1, dtype=np.int64)
+    np.maximum.at(owner, tgt, src)
+    r = np.zeros(n)
+    has = owner >= 0
+    r[has] = i1.reshape(-1)[has] - i0.reshape(-1)[owner[has]]
+
+    g = J.T @ r
+    Hm = J.T @ J
+    return g, Hm, r, J
+
+
+def optimize(pyr, K, cfg, init_state=None):
+    """cfg: dict(num_levels, lam, max_iter, min_grad, min_depth, max_depth).
+    Returns (state, iterations_per_level, trace list)."""
+    state = np.zeros(6) if init_state is None else np.array(init_state, dtype=np.float64)
+    g = np.zeros(6)
+    iters = [0] * cfg["num_levels"]
+    trace = []
+    for level in range(cfg["num_levels"] - 1, -1, -1):
+        it = 0
+        while True:
+            if cfg["max_iter"][level] > 0:
+                g, Hm, _, _ = normal_equations(pyr[level], level, K, state,
+                                               cfg.get("min_depth", 0.3), cfg.get("max_depth", 5.0))
+                state = state - cfg["lam"][level] * np.linalg.solve(Hm, g)
+                trace.append(dict(level=level, iteration=it + 1, gradient=g.copy(),
+                                  hessian=Hm.copy(), state=state.copy()))
+            it += 1
+            if it >= cfg["max_iter"][level]:
+                break
+            if np.linalg.norm(g) < cfg["min_grad"][level]:
+                break
+        iters[level] = it
+    return state, iters, trace

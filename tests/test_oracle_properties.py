@@ -1,0 +1,133 @@
+"""Size-independent properties and edge cases of the oracle."""
+import numpy as np
+
+import phovo_amd  # noqa: F401
+from phovo_amd import se3, synthetic
+from oracle import oracle, numpy_twin as twin
+
+
+def _cfg(**kw):
+    base = dict(num_levels=3, max_iter=[2, 3, 5], min_grad=[0, 0, 0], lam=[1, 1, 1],
+                grad_scale=[0.0625] * 3, blur=[0, 0, 0])
+    base.update(kw)
+    return oracle.make_config(**base)
+
+
+def test_defaults_match_reference_constructor():
+    # ...Analytic.h:430-443
+    cfg = oracle.make_config()
+    assert cfg.num_levels == 5
+    assert list(cfg.max_num_iterations[:5]) == [0, 0, 5, 20, 50]
+    assert list(cfg.min_gradient_norm[:5]) == [300.0] * 5
+    assert list(cfg.image_gradients_scaling_factor[:5]) == [0.0625] * 5
+    assert (cfg.min_depth, cfg.max_depth) == (0.3, 5.0)
+
+
+def test_identical_frames_keep_zero_state():
+    p = synthetic.make_pair(3, 64, 48)
+    state, iters = oracle.align_frames(_cfg(), p["K"], p["gray0"], p["depth0"], p["gray0"])
+    assert np.all(state == 0.0)
+    assert iters == [2, 3, 5]
+
+
+def test_levels_with_zero_iterations_leave_state_untouched():
+    p = synthetic.make_pair(4, 64, 48)
+    init = np.array([0.01, -0.02, 0.005, 0.003, -0.002, 0.001])
+    state, iters = oracle.align_frames(_cfg(max_iter=[0, 0, 0]), p["K"], p["gray0"], p["depth0"],
+                                       p["gray1"], init_state=init)
+    assert np.array_equal(state, init)
+    assert iters == [1, 1, 1]            # the loop body runs once per level (:510,547-549)
+
+
+def test_scatter_last_writer_wins_and_jacobian_at_source_index():
+    # 4x1 image, all four source pixels are sent to column 2: the LAST one (c=3) must own r[2].
+    w, h = 4, 1
+    K = np.array([[1.0, 0, 0.0], [0, 1.0, 0.0], [0, 0, 1]])
+    i0 = np.array([[0.1, 0.2, 0.3, 0.4]])
+    i1 = np.array([[0.5, 0.6, 0.7, 0.8]])
+    # depth z, state x: tc = (c*z + x)/z ; choose x so that every pixel lands near 2
+    d0 = np.array([[1.0, 1.0, 1.0, 1.0]])
+    gx = np.array([[1.0, 2.0, 3.0, 4.0]])
+    gy = np.zeros((1, 4))
+    # collapse all columns: use a large depth-dependent trick instead -> state x = 0 keeps identity,
+    # so build the collision with depth: px = c*z, X = px + x, tc = X/z.  z=1 except pixel 0 (z=0.5, x=1 -> tc=2)
+    d0 = np.array([[0.5, 1.0, 1.0, 1.0]])
+    state = np.array([1.0, 0, 0, 0, 0, 0])
+    r, J = oracle.compute_residuals_and_jacobians(i0, d0, i1, gx, gy, 0, K, state, 0.3, 5.0)
+    # pixel 0: tc = (0*0.5+1)/0.5 = 2 ; pixel 1: tc = 2 ; pixel 2: tc = 3 ; pixel 3: tc = 4 (out)
+    assert r[2] == i1[0, 2] - i0[0, 1]          # pixel 1 (later) wins over pixel 0
+    assert r[3] == i1[0, 3] - i0[0, 2]
+    assert r[0] == 0 and r[1] == 0
+    # Jacobian rows live at the SOURCE index; pixel 3 is out of bounds -> zero row
+    assert np.all(J[:, 3] == 0)
+    assert J[0, 0] == gx[0, 0] * (1.0 / 0.5) and J[0, 1] == gx[0, 1] * 1.0
+    g, Hm, r2, J2 = twin.normal_equations((i0, d0, i1, gx, gy), 0, K, state)
+    np.testing.assert_allclose(r, r2, atol=0)
+    np.testing.assert_allclose(J.T, J2, rtol=1e-15)
+
+
+def test_depth_gate_is_strict():
+    # minD < z < maxD, strict on both sides (:280)
+    K = np.eye(3)
+    i0 = np.full((1, 3), 0.5)
+    i1 = np.full((1, 3), 0.25)
+    d0 = np.array([[0.3, 1.0, 5.0]])
+    ones = np.ones((1, 3))
+    r, J = oracle.compute_residuals_and_jacobians(i0, d0, i1, ones, ones, 0, K, np.zeros(6), 0.3, 5.0)
+    assert r[0] == 0 and r[2] == 0 and r[1] == -0.25
+    assert np.all(J[:, 0] == 0) and np.all(J[:, 2] == 0) and np.any(J[:, 1] != 0)
+
+
+def test_c_round_half_away_from_zero():
+    # tc = c + x; x = 0.5 sends pixel c to c+1 (round(0.5)=1, round(1.5)=2), not banker's rounding
+    K = np.eye(3)
+    i0 = np.array([[0.1, 0.2, 0.3, 0.4]])
+    i1 = np.array([[0.5, 0.6, 0.7, 0.9]])
+    d0 = np.ones((1, 4))
+    z = np.zeros((1, 4))
+    r, _ = oracle.compute_residuals_and_jacobians(i0, d0, i1, z, z, 0, K,
+                                                  np.array([0.5, 0, 0, 0, 0, 0]), 0.3, 5.0)
+    np.testing.assert_allclose(r, [0, 0.6 - 0.1, 0.7 - 0.2, 0.9 - 0.3], atol=1e-16)
+
+
+def test_transcription_bug_is_reproduced():
+    # With x != 0 the (u,z) entry uses px*(cp*cy + x) instead of px*cp*cy + x  (:253,:325)
+    K = np.array([[100.0, 0, 2.0], [0, 100.0, 2.0], [0, 0, 1]])
+    n = 5
+    i0 = np.zeros((n, n)); i1 = np.zeros((n, n))
+    d0 = np.full((n, n), 2.0)
+    gx = np.ones((n, n)); gy = np.zeros((n, n))
+    state = np.array([0.01, 0.0, 0.0, 0.0, 0.0, 0.0])
+    _, J = oracle.compute_residuals_and_jacobians(i0, d0, i1, gx, gy, 0, K, state, 0.3, 5.0)
+    c = 3; r_ = 2; i = r_ * n + c
+    px = (c - 2.0) * 2.0 / 100.0
+    Z = 2.0
+    buggy = -100.0 * (2.0 * 0.0 + 0.0 + px * (1.0 + 0.01)) / Z ** 2
+    true = -100.0 * (px * 1.0 + 0.01) / Z ** 2
+    assert abs(J[2, i] - buggy) < 1e-15
+    assert abs(J[2, i] - true) > 1e-6
+
+
+def test_oracle_and_twin_agree_on_random_problem():
+    p = synthetic.make_pair(11, 80, 60, holes=0.03)
+    cfg = _cfg()
+    s1, it1 = oracle.align_frames(cfg, p["K"], p["gray0"], p["depth0"], p["gray1"])
+    pyr = twin.build_pyramids(p["gray0"], p["depth0"], p["gray1"], 3, [0.0625] * 3)
+    # 80x60 is divisible by 4
+    s2, it2, _ = twin.optimize(pyr, p["K"], dict(num_levels=3, lam=[1, 1, 1], max_iter=[2, 3, 5],
+                                                  min_grad=[0, 0, 0]))
+    assert it1 == it2
+    assert se3.state_distance(s1, s2) < 1e-9
+
+
+def test_warp_image_truncates_and_gates_on_positive_depth():
+    # CPhotoconsistencyOdometry.h:107,119-122
+    K = np.eye(3)
+    g = np.array([[10, 20, 30, 40]], dtype=np.uint8)
+    d = np.array([[1.0, 0.0, 1.0, 1.0]])
+    rt = np.eye(4); rt[0, 3] = 0.9            # tc = c + 0.9 -> truncated to c
+    out = oracle.warp_image(g, d, rt, K)
+    assert list(out[0]) == [10, 0, 30, 40]
+    rt[0, 3] = 1.0
+    out = oracle.warp_image(g, d, rt, K)
+    assert list(out[0]) == [0, 10, 0, 30]
