@@ -1,0 +1,190 @@
+/*
+ * phovo_hip.h -- C ABI of the MI355X-native analytic Gauss-Newton RGB-D alignment path.
+ *
+ * This is the drop-in boundary for ONE path of MiguelAlgaba/photoconsistency-visual-odometry:
+ *   phovo::Analytic::CPhotoconsistencyOdometryAnalytic<unsigned char,double>
+ *   (phovo/include/CPhotoconsistencyOdometryAnalytic.h:57-608), i.e. the abstract surface of
+ *   phovo/include/CPhotoconsistencyOdometry.h:137-179 plus SetMinDepth/SetMaxDepth/
+ *   ReadConfigurationFile.
+ * The reference has no FFI: its "plugin API" is that C++ template class.  The functions
+ * below are what a binding of that class binds (include/phovo/CPhotoconsistencyOdometryAnalytic.h
+ * in this repository is such a binding; INTEGRATION.md shows it next to the reference's apps).
+ * Plain pointers and sizes only; every function returns a phovo_status (0 = ok) and never throws.
+ * All images are row-major; strides are in BYTES; the library copies what it is given (the
+ * caller keeps ownership of every buffer, as with the reference's const& arguments,
+ * ...Analytic.h:466-491).  All arithmetic is fp64 on the device.
+ *
+ * Two layers:
+ *   phovo_odometry_*  one frame pair at a time -- 1:1 with the reference's methods.
+ *   phovo_engine_*    the batched form the throughput path uses: a pool of frames whose
+ *                     pyramids live in HBM and a list of (source, target) frame pairs that
+ *                     are aligned by one launch per active pyramid level.
+ * A process drives one engine per GPU; engines are independent (one HIP stream each).
+ */
+#ifndef PHOVO_HIP_H
+#define PHOVO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PHOVO_MAX_LEVELS 16
+
+typedef enum phovo_status {
+  PHOVO_OK = 0,
+  PHOVO_E_INVALID_ARGUMENT = 1,  /* NULL pointer, index out of range                         */
+  PHOVO_E_CONFIG = 2,            /* missing / malformed key, per-level array too short        */
+  PHOVO_E_SHAPE = 3,             /* frame size does not match the pool, level too large       */
+  PHOVO_E_HIP = 4,               /* a HIP runtime call failed (message: phovo_last_error())   */
+  PHOVO_E_NOT_READY = 5,         /* call order violated (e.g. Optimize before Set*Frame)      */
+  PHOVO_E_IO = 6,                /* file cannot be opened                                     */
+  PHOVO_E_UNSUPPORTED = 7        /* a mode the device path does not implement                 */
+} phovo_status;
+
+/* Flags in phovo_pair_report.flags */
+#define PHOVO_PAIR_NONFINITE 1u  /* J^T J was singular / the state became inf or NaN: the reference
+                                    propagates inf/NaN silently (...Analytic.h:540); so does this
+                                    library, but it says so here.                                 */
+
+/* The per-level parameter vectors of the reference (...Analytic.h:91-103), as filled by
+ * ReadConfigurationFile (:581-607) or by the constructor defaults (:430-443). */
+typedef struct phovo_config {
+  int    num_levels;                                       /* numOptimizationLevels                      */
+  int    blur_filter_size[PHOVO_MAX_LEVELS];               /* blurFilterSize (at each level)             */
+  double image_gradients_scaling_factor[PHOVO_MAX_LEVELS]; /* imageGradientsScalingFactor (at each level)*/
+  double lambda_optimization_step[PHOVO_MAX_LEVELS];       /* lambda_optimization_step (at each level)   */
+  int    max_num_iterations[PHOVO_MAX_LEVELS];             /* max_num_iterations (at each level)         */
+  double min_gradient_norm[PHOVO_MAX_LEVELS];              /* min_gradient_norm (at each level)          */
+  int    visualize_iterations;                             /* visualizeIterations (headless: ignored)    */
+} phovo_config;
+
+/* What Optimize() did for one pair (the reference only prints this behind
+ * ENABLE_PRINT_CONSOLE_OPTIMIZATION_PROGRESS, ...Analytic.h:396-422). */
+typedef struct phovo_pair_report {
+  int      iterations[PHOVO_MAX_LEVELS]; /* m_Iteration when each level stopped (:547-549)      */
+  double   gradient_norm;                /* ||J^T r|| of the last executed iteration (:380)      */
+  uint32_t flags;                        /* PHOVO_PAIR_*                                         */
+  uint32_t reserved;
+} phovo_pair_report;
+
+typedef struct phovo_engine phovo_engine;
+typedef struct phovo_odometry phovo_odometry;
+
+/* ---- library ---------------------------------------------------------------------------- */
+const char *phovo_version(void);
+const char *phovo_status_string(int status);
+/* Message of the most recent failure on the calling thread ("" if none). */
+const char *phovo_last_error(void);
+/* Number of HIP devices visible (0 if none / no driver). */
+int phovo_device_count(void);
+
+/* ---- configuration: ...Analytic.h:430-443 (defaults), :581-607 (ReadConfigurationFile) ---- */
+int phovo_config_default(phovo_config *cfg);
+/* Parses the reference's config_files/ *.yml unchanged (OpenCV FileStorage "%YAML:1.0" dialect,
+ * keys with spaces and parentheses, per-level arrays that may be longer than num_levels). */
+int phovo_config_read_file(const char *path, phovo_config *cfg);
+
+/* eigenPose, CPhotoconsistencyOdometry.h:47-71: (x,y,z,yaw,pitch,roll) -> row-major 4x4. */
+int phovo_eigen_pose(const double state[6], double rt[16]);
+
+/* ---- single pair: 1:1 with CPhotoconsistencyOdometryAnalytic<unsigned char,double> ------- */
+int phovo_odometry_create(int device, phovo_odometry **out);               /* ctor  :430-443 */
+int phovo_odometry_destroy(phovo_odometry *o);                             /* dtor  :445     */
+int phovo_odometry_read_configuration_file(phovo_odometry *o, const char *path);   /* :581 */
+int phovo_odometry_set_config(phovo_odometry *o, const phovo_config *cfg);
+int phovo_odometry_set_min_depth(phovo_odometry *o, double min_depth);     /* :448 */
+int phovo_odometry_set_max_depth(phovo_odometry *o, double max_depth);     /* :454 */
+int phovo_odometry_set_intrinsic_matrix(phovo_odometry *o, const double k[9]);     /* :460, row-major 3x3 */
+/* SetSourceFrame :466-476 -- intensity u8, depth fp64 metres; builds the intensity and depth pyramids. */
+int phovo_odometry_set_source_frame(phovo_odometry *o,
+                                    const uint8_t *intensity, size_t intensity_stride,
+                                    const double *depth, size_t depth_stride,
+                                    int width, int height);
+/* SetTargetFrame :479-491 -- depth is ignored (may be NULL); builds intensity + Scharr pyramids. */
+int phovo_odometry_set_target_frame(phovo_odometry *o,
+                                    const uint8_t *intensity, size_t intensity_stride,
+                                    const double *depth, size_t depth_stride,
+                                    int width, int height);
+int phovo_odometry_set_initial_state_vector(phovo_odometry *o, const double state[6]);     /* :494 */
+int phovo_odometry_optimize(phovo_odometry *o);                                            /* :500 */
+int phovo_odometry_get_optimal_state_vector(const phovo_odometry *o, double state[6]);     /* :566 */
+int phovo_odometry_get_optimal_rigid_transformation_matrix(const phovo_odometry *o, double rt[16]); /* :572 */
+int phovo_odometry_get_report(const phovo_odometry *o, phovo_pair_report *report);
+/* Device time of the last Optimize() in milliseconds (HIP events; the reference wraps the same
+ * call in cv::TickMeter, apps/PhotoconsistencyFrameAlignment/PhotoconsistencyFrameAlignment.cpp:99-102). */
+int phovo_odometry_last_optimize_ms(const phovo_odometry *o, double *ms);
+
+/* ---- batched engine ------------------------------------------------------------------------ */
+#define PHOVO_ROLE_SOURCE 1   /* needs intensity + depth pyramids   (SetSourceFrame) */
+#define PHOVO_ROLE_TARGET 2   /* needs intensity + gradient pyramids (SetTargetFrame) */
+#define PHOVO_ROLE_BOTH   3
+
+int phovo_engine_create(int device, phovo_engine **out);
+int phovo_engine_destroy(phovo_engine *e);
+int phovo_engine_set_config(phovo_engine *e, const phovo_config *cfg);
+int phovo_engine_get_config(const phovo_engine *e, phovo_config *cfg);
+int phovo_engine_set_intrinsic_matrix(phovo_engine *e, const double k[9]);
+int phovo_engine_set_depth_range(phovo_engine *e, double min_depth, double max_depth);
+/* 0 (default): only levels with max_num_iterations > 0 are built and kept in HBM (the others are
+ * never read by Optimize()).  1: every level, as the reference does (:474-475,487-490). */
+int phovo_engine_set_build_all_levels(phovo_engine *e, int on);
+
+/* (Re)allocates the frame pool: n_frames frames of width x height.  Uses the current config. */
+int phovo_engine_reserve_frames(phovo_engine *e, int n_frames, int width, int height);
+int phovo_engine_level_size(const phovo_engine *e, int level, int *width, int *height);
+/* 1 if `level` is resident in the pool. */
+int phovo_engine_level_is_stored(const phovo_engine *e, int level);
+
+/* Copies one raw frame to the device and builds its pyramids there. depth may be NULL for a
+ * pure target frame. */
+int phovo_engine_upload_frame(phovo_engine *e, int frame, int roles,
+                              const uint8_t *intensity, size_t intensity_stride,
+                              const double *depth, size_t depth_stride);
+/* Same with 16-bit depth (TUM / Kinect PNG) converted on the device as double(u16) * depth_scale
+ * (apps/PhotoconsistencyVisualOdometry/PhotoconsistencyVisualOdometry.cpp:163,208,220). */
+int phovo_engine_upload_frame_u16(phovo_engine *e, int frame, int roles,
+                                  const uint8_t *intensity, size_t intensity_stride,
+                                  const uint16_t *depth, size_t depth_stride, double depth_scale);
+/* Direct access to the fp64 planes of one level of one frame (w*h doubles each, NULL = skip):
+ * lets a caller supply pyramids built elsewhere (e.g. by OpenCV) or read back the device-built ones. */
+int phovo_engine_set_level_planes(phovo_engine *e, int frame, int level,
+                                  const double *intensity, const double *depth,
+                                  const double *grad_x, const double *grad_y);
+int phovo_engine_get_level_planes(const phovo_engine *e, int frame, int level,
+                                  double *intensity, double *depth,
+                                  double *grad_x, double *grad_y);
+
+/* Optimize() for n_pairs independent (source, target) frame pairs.
+ *   init_states  n_pairs x 6 (SetInitialStateVector) or NULL for all-zero
+ *   out_states   n_pairs x 6 optimal state vectors
+ *   reports      n_pairs entries or NULL
+ * Synchronous: returns when the results are in host memory. */
+int phovo_engine_align_pairs(phovo_engine *e, int n_pairs,
+                             const int *source_frames, const int *target_frames,
+                             const double *init_states, double *out_states,
+                             phovo_pair_report *reports);
+/* Split form: enqueue on the engine's stream without waiting, then wait, then fetch. */
+int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs,
+                               const int *source_frames, const int *target_frames,
+                               const double *init_states);
+int phovo_engine_synchronize(phovo_engine *e);
+int phovo_engine_fetch_results(phovo_engine *e, int n_pairs, double *out_states,
+                               phovo_pair_report *reports);
+/* Device pointer to the n_pairs x 6 fp64 result of the last enqueue (for an RCCL gather). */
+int phovo_engine_results_device_ptr(phovo_engine *e, void **states);
+
+/* Device time (ms, HIP events on the engine's stream) of the last enqueue: total over the
+ * per-level launches, and per level (0 for levels that were not launched). */
+int phovo_engine_last_align_ms(const phovo_engine *e, double *total_ms,
+                               double level_ms[PHOVO_MAX_LEVELS]);
+/* Launch geometry chosen for `level`: threads per workgroup and dynamic LDS bytes. */
+int phovo_engine_level_launch_info(const phovo_engine *e, int level, int *threads, int *lds_bytes,
+                                   int *owner_in_lds, int *source_in_lds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,825 @@
+// Host side of the C ABI (include/phovo_hip.h): frame pool in HBM, per-level launches of the
+// Gauss-Newton kernel, and the single-pair wrapper that mirrors
+// phovo::Analytic::CPhotoconsistencyOdometryAnalytic (CPhotoconsistencyOdometryAnalytic.h:428-607).
+// There is no CPU fallback anywhere in this file: without a HIP device every entry point that
+// touches data fails with PHOVO_E_HIP.
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "phovo_internal.hpp"
+
+namespace phovo_hip {
+
+static thread_local std::string g_last_error;
+
+void set_last_error(const std::string &msg) { g_last_error = msg; }
+int fail(int status, const std::string &msg) { g_last_error = msg; return status; }
+
+#define PHOVO_HIP_CHECK(expr)                                                                   \
+  do {                                                                                          \
+    hipError_t _e = (expr);                                                                     \
+    if (_e != hipSuccess)                                                                       \
+      return fail(PHOVO_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));              \
+  } while (0)
+
+struct LevelPool {
+  int w = 0, h = 0, n = 0;
+  bool stored = false;
+  double *planes = nullptr;      // [frames][4][n]
+  GNLaunchPlan plan{};
+  bool plan_ok = false;
+};
+
+}  // namespace phovo_hip
+
+using namespace phovo_hip;
+
+struct phovo_engine {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_start[PHOVO_MAX_LEVELS] = {};
+  hipEvent_t ev_stop[PHOVO_MAX_LEVELS] = {};
+  bool level_launched[PHOVO_MAX_LEVELS] = {};
+  bool have_timing = false;
+
+  phovo_config cfg{};
+  double K[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  bool have_K = false;
+  double min_depth = 0.3, max_depth = 5.0;     // ...Analytic.h:430
+  bool build_all = false;
+
+  int n_frames = 0, width = 0, height = 0;
+  LevelPool levels[PHOVO_MAX_LEVELS];
+  uint8_t *d_gray = nullptr;
+  double *d_depth = nullptr;
+  uint16_t *d_depth16 = nullptr;
+  double *d_tmp = nullptr;
+  double *d_blur_kernel = nullptr;             // [levels][max ksize]
+  int blur_kernel_stride = 0;
+
+  int pair_capacity = 0;
+  int *d_src = nullptr, *d_tgt = nullptr;
+  double *d_states = nullptr;
+  phovo_pair_report *d_reports = nullptr;
+  int *d_owner = nullptr;
+  size_t owner_capacity = 0;
+  int last_pairs = 0;
+};
+
+namespace {
+
+void free_pool(phovo_engine *e)
+{
+  for (auto &lv : e->levels) {
+    if (lv.planes) (void)hipFree(lv.planes);
+    lv = LevelPool{};
+  }
+  if (e->d_gray) (void)hipFree(e->d_gray);
+  if (e->d_depth) (void)hipFree(e->d_depth);
+  if (e->d_depth16) (void)hipFree(e->d_depth16);
+  if (e->d_tmp) (void)hipFree(e->d_tmp);
+  if (e->d_blur_kernel) (void)hipFree(e->d_blur_kernel);
+  e->d_gray = nullptr; e->d_depth = nullptr; e->d_depth16 = nullptr; e->d_tmp = nullptr;
+  e->d_blur_kernel = nullptr;
+  e->n_frames = 0; e->width = 0; e->height = 0;
+}
+
+void free_pairs(phovo_engine *e)
+{
+  if (e->d_src) (void)hipFree(e->d_src);
+  if (e->d_tgt) (void)hipFree(e->d_tgt);
+  if (e->d_states) (void)hipFree(e->d_states);
+  if (e->d_reports) (void)hipFree(e->d_reports);
+  if (e->d_owner) (void)hipFree(e->d_owner);
+  e->d_src = e->d_tgt = nullptr; e->d_states = nullptr; e->d_reports = nullptr; e->d_owner = nullptr;
+  e->pair_capacity = 0; e->owner_capacity = 0;
+}
+
+int validate_config(const phovo_config *c)
+{
+  if (c->num_levels < 1 || c->num_levels > PHOVO_MAX_LEVELS)
+    return fail(PHOVO_E_CONFIG, "num_levels out of range [1, 16]");
+  for (int l = 0; l < c->num_levels; l++) {
+    if (c->max_num_iterations[l] < 0) return fail(PHOVO_E_CONFIG, "max_num_iterations < 0");
+    const int b = c->blur_filter_size[l];
+    if (b < 0 || (b > 0 && (b % 2) == 0))
+      return fail(PHOVO_E_CONFIG, "blurFilterSize must be 0 or odd (cv::GaussianBlur requires an odd kernel)");
+    if (b > 63) return fail(PHOVO_E_CONFIG, "blurFilterSize > 63");
+  }
+  return PHOVO_OK;
+}
+
+void level_dims(int w, int h, int level, int *lw, int *lh)
+{
+  const double f = 1.0 / (double)(1 << level);        // factor = factor/2  (...Analytic.h:161)
+  *lw = (int)std::rint((double)w * f);                // Size(0,0), fx, fy -> cvRound(cols*fx)
+  *lh = (int)std::rint((double)h * f);
+}
+
+int ensure_pairs(phovo_engine *e, int n_pairs)
+{
+  if (n_pairs <= e->pair_capacity) return PHOVO_OK;
+  const size_t keep_owner = e->owner_capacity;
+  int *keep = e->d_owner;
+  e->d_owner = nullptr;
+  free_pairs(e);
+  e->d_owner = keep; e->owner_capacity = keep_owner;
+  PHOVO_HIP_CHECK(hipMalloc(&e->d_src, sizeof(int) * (size_t)n_pairs));
+  PHOVO_HIP_CHECK(hipMalloc(&e->d_tgt, sizeof(int) * (size_t)n_pairs));
+  PHOVO_HIP_CHECK(hipMalloc(&e->d_states, sizeof(double) * 6 * (size_t)n_pairs));
+  PHOVO_HIP_CHECK(hipMalloc(&e->d_reports, sizeof(phovo_pair_report) * (size_t)n_pairs));
+  e->pair_capacity = n_pairs;
+  return PHOVO_OK;
+}
+
+int build_frame_pyramids(phovo_engine *e, int frame, int roles)
+{
+  const int w = e->width, h = e->height;
+  for (int l = 0; l < e->cfg.num_levels; l++) {
+    LevelPool &lv = e->levels[l];
+    if (!lv.stored) continue;
+    double *base = lv.planes + (size_t)frame * PLANES_PER_FRAME * (size_t)lv.n;
+    double *pi = base + (size_t)PLANE_I * lv.n, *pd = base + (size_t)PLANE_D * lv.n;
+    double *pgx = base + (size_t)PLANE_GX * lv.n, *pgy = base + (size_t)PLANE_GY * lv.n;
+    // BuildPyramid(intensity, applyBlur = true)  :474,487
+    PHOVO_HIP_CHECK(pyr_intensity_level(e->d_gray, w, h, l, lv.w, lv.h, pi, e->stream));
+    const int ks = e->cfg.blur_filter_size[l];
+    if (ks > 0) {                                                       // GaussianBlur twice  :144-148
+      const double *kern = e->d_blur_kernel + (size_t)l * e->blur_kernel_stride;
+      PHOVO_HIP_CHECK(pyr_gaussian_blur(pi, e->d_tmp, lv.w, lv.h, ks, kern, e->stream));
+      PHOVO_HIP_CHECK(pyr_gaussian_blur(pi, e->d_tmp, lv.w, lv.h, ks, kern, e->stream));
+    }
+    if (roles & PHOVO_ROLE_SOURCE)                                      // BuildPyramid(depth, false)  :475
+      PHOVO_HIP_CHECK(pyr_depth_level(e->d_depth, w, h, l, lv.w, lv.h, pd, e->stream));
+    if (roles & PHOVO_ROLE_TARGET)                                      // BuildDerivativesPyramids  :490
+      PHOVO_HIP_CHECK(pyr_scharr(pi, lv.w, lv.h, e->cfg.image_gradients_scaling_factor[l], pgx, pgy, e->stream));
+  }
+  return PHOVO_OK;
+}
+
+int copy_rows_to_device(void *dst, const void *src, size_t stride, size_t row_bytes, int rows,
+                        hipStream_t stream)
+{
+  if (stride == row_bytes) {
+    PHOVO_HIP_CHECK(hipMemcpyAsync(dst, src, row_bytes * (size_t)rows, hipMemcpyHostToDevice, stream));
+  } else {
+    if (stride < row_bytes) return fail(PHOVO_E_INVALID_ARGUMENT, "stride smaller than a row");
+    PHOVO_HIP_CHECK(hipMemcpy2DAsync(dst, row_bytes, src, stride, row_bytes, (size_t)rows,
+                                     hipMemcpyHostToDevice, stream));
+  }
+  return PHOVO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *phovo_version(void) { return "phovo-hip 0.1.0 (gfx950)"; }
+
+const char *phovo_status_string(int status)
+{
+  switch (status) {
+    case PHOVO_OK: return "ok";
+    case PHOVO_E_INVALID_ARGUMENT: return "invalid argument";
+    case PHOVO_E_CONFIG: return "configuration error";
+    case PHOVO_E_SHAPE: return "shape error";
+    case PHOVO_E_HIP: return "HIP runtime error";
+    case PHOVO_E_NOT_READY: return "not ready (call order)";
+    case PHOVO_E_IO: return "I/O error";
+    case PHOVO_E_UNSUPPORTED: return "unsupported";
+    default: return "unknown status";
+  }
+}
+
+const char *phovo_last_error(void) { return g_last_error.c_str(); }
+
+int phovo_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int phovo_config_default(phovo_config *cfg)
+{
+  if (!cfg) return fail(PHOVO_E_INVALID_ARGUMENT, "phovo_config_default: null");
+  std::memset(cfg, 0, sizeof(*cfg));
+  cfg->num_levels = 5;                                   // ...Analytic.h:433
+  for (int l = 0; l < PHOVO_MAX_LEVELS; l++) {
+    cfg->blur_filter_size[l] = 0;                        // :434
+    cfg->image_gradients_scaling_factor[l] = 0.0625;     // :435
+    cfg->lambda_optimization_step[l] = 1.0;              // :436
+    cfg->max_num_iterations[l] = 0;                      // :437
+    cfg->min_gradient_norm[l] = 300.0;                   // :441
+  }
+  cfg->max_num_iterations[2] = 5;                        // :438
+  cfg->max_num_iterations[3] = 20;                       // :439
+  cfg->max_num_iterations[4] = 50;                       // :440
+  cfg->visualize_iterations = 0;                         // :442
+  return PHOVO_OK;
+}
+
+int phovo_config_read_file(const char *path, phovo_config *cfg) { return read_config_file(path, cfg); }
+
+int phovo_eigen_pose(const double s[6], double rt[16])
+{
+  if (!s || !rt) return fail(PHOVO_E_INVALID_ARGUMENT, "phovo_eigen_pose: null");
+  const double x = s[0], y = s[1], z = s[2], yaw = s[3], pitch = s[4], roll = s[5];
+  rt[0] = std::cos(yaw) * std::cos(pitch);               // CPhotoconsistencyOdometry.h:52-70
+  rt[1] = std::cos(yaw) * std::sin(pitch) * std::sin(roll) - std::sin(yaw) * std::cos(roll);
+  rt[2] = std::cos(yaw) * std::sin(pitch) * std::cos(roll) + std::sin(yaw) * std::sin(roll);
+  rt[3] = x;
+  rt[4] = std::sin(yaw) * std::cos(pitch);
+  rt[5] = std::sin(yaw) * std::sin(pitch) * std::sin(roll) + std::cos(yaw) * std::cos(roll);
+  rt[6] = std::sin(yaw) * std::sin(pitch) * std::cos(roll) - std::cos(yaw) * std::sin(roll);
+  rt[7] = y;
+  rt[8] = -std::sin(pitch);
+  rt[9] = std::cos(pitch) * std::sin(roll);
+  rt[10] = std::cos(pitch) * std::cos(roll);
+  rt[11] = z;
+  rt[12] = 0; rt[13] = 0; rt[14] = 0; rt[15] = 1;
+  return PHOVO_OK;
+}
+
+/* ------------------------------------------------------------------ engine ------------------ */
+
+int phovo_engine_create(int device, phovo_engine **out)
+{
+  if (!out) return fail(PHOVO_E_INVALID_ARGUMENT, "phovo_engine_create: null");
+  *out = nullptr;
+  int count = 0;
+  hipError_t err = hipGetDeviceCount(&count);
+  if (err != hipSuccess || count <= 0)
+    return fail(PHOVO_E_HIP, "no HIP device available: this library has no CPU path");
+  if (device < 0 || device >= count) return fail(PHOVO_E_INVALID_ARGUMENT, "device index out of range");
+  PHOVO_HIP_CHECK(hipSetDevice(device));
+  phovo_engine *e = new (std::nothrow) phovo_engine();
+  if (!e) return fail(PHOVO_E_INVALID_ARGUMENT, "out of host memory");
+  e->device = device;
+  phovo_config_default(&e->cfg);
+  hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+  if (he == hipSuccess) {
+    for (int l = 0; l < PHOVO_MAX_LEVELS && he == hipSuccess; l++) {
+      he = hipEventCreate(&e->ev_start[l]);
+      if (he == hipSuccess) he = hipEventCreate(&e->ev_stop[l]);
+    }
+  }
+  if (he == hipSuccess) he = gn_prepare_kernels();
+  if (he != hipSuccess) {
+    phovo_engine_destroy(e);
+    return fail(PHOVO_E_HIP, std::string("engine setup: ") + hipGetErrorString(he));
+  }
+  *out = e;
+  return PHOVO_OK;
+}
+
+int phovo_engine_destroy(phovo_engine *e)
+{
+  if (!e) return PHOVO_OK;
+  (void)hipSetDevice(e->device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  free_pool(e);
+  free_pairs(e);
+  for (int l = 0; l < PHOVO_MAX_LEVELS; l++) {
+    if (e->ev_start[l]) (void)hipEventDestroy(e->ev_start[l]);
+    if (e->ev_stop[l]) (void)hipEventDestroy(e->ev_stop[l]);
+  }
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+  return PHOVO_OK;
+}
+
+int phovo_engine_set_config(phovo_engine *e, const phovo_config *cfg)
+{
+  if (!e || !cfg) return fail(PHOVO_E_INVALID_ARGUMENT, "set_config: null");
+  const int st = validate_config(cfg);
+  if (st != PHOVO_OK) return st;
+  // A new configuration changes which levels exist and how they are built: drop the pool, as the
+  // reference requires the configuration before Set*Frame (:474 uses m_NumOptimizationLevels).
+  (void)hipSetDevice(e->device);
+  (void)hipStreamSynchronize(e->stream);
+  free_pool(e);
+  e->cfg = *cfg;
+  return PHOVO_OK;
+}
+
+int phovo_engine_get_config(const phovo_engine *e, phovo_config *cfg)
+{
+  if (!e || !cfg) return fail(PHOVO_E_INVALID_ARGUMENT, "get_config: null");
+  *cfg = e->cfg;
+  return PHOVO_OK;
+}
+
+int phovo_engine_set_intrinsic_matrix(phovo_engine *e, const double k[9])
+{
+  if (!e || !k) return fail(PHOVO_E_INVALID_ARGUMENT, "set_intrinsic_matrix: null");
+  std::memcpy(e->K, k, sizeof(e->K));
+  e->have_K = true;
+  return PHOVO_OK;
+}
+
+int phovo_engine_set_depth_range(phovo_engine *e, double min_depth, double max_depth)
+{
+  if (!e) return fail(PHOVO_E_INVALID_ARGUMENT, "set_depth_range: null");
+  e->min_depth = min_depth;
+  e->max_depth = max_depth;
+  return PHOVO_OK;
+}
+
+int phovo_engine_set_build_all_levels(phovo_engine *e, int on)
+{
+  if (!e) return fail(PHOVO_E_INVALID_ARGUMENT, "set_build_all_levels: null");
+  if ((on != 0) != e->build_all) {
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    free_pool(e);
+  }
+  e->build_all = on != 0;
+  return PHOVO_OK;
+}
+
+int phovo_engine_reserve_frames(phovo_engine *e, int n_frames, int width, int height)
+{
+  if (!e) return fail(PHOVO_E_INVALID_ARGUMENT, "reserve_frames: null");
+  if (n_frames < 1 || width < 1 || height < 1) return fail(PHOVO_E_INVALID_ARGUMENT, "reserve_frames: sizes must be positive");
+  PHOVO_HIP_CHECK(hipSetDevice(e->device));
+  PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
+  free_pool(e);
+  size_t max_n = 0;
+  int max_ks = 0;
+  for (int l = 0; l < e->cfg.num_levels; l++) {
+    LevelPool &lv = e->levels[l];
+    level_dims(width, height, l, &lv.w, &lv.h);
+    if (lv.w < 1 || lv.h < 1) { free_pool(e); return fail(PHOVO_E_SHAPE, "image too small for the number of pyramid levels"); }
+    lv.n = lv.w * lv.h;
+    lv.stored = e->build_all || e->cfg.max_num_iterations[l] > 0;
+    lv.plan_ok = gn_plan_level(lv.n, &lv.plan);
+    if (lv.stored) {
+      const size_t bytes = sizeof(double) * (size_t)n_frames * PLANES_PER_FRAME * (size_t)lv.n;
+      hipError_t he = hipMalloc(&lv.planes, bytes);
+      if (he != hipSuccess) { free_pool(e); return fail(PHOVO_E_HIP, std::string("hipMalloc(frame pool): ") + hipGetErrorString(he)); }
+      he = hipMemsetAsync(lv.planes, 0, bytes, e->stream);
+      if (he != hipSuccess) { free_pool(e); return fail(PHOVO_E_HIP, std::string("hipMemset(frame pool): ") + hipGetErrorString(he)); }
+      if ((size_t)lv.n > max_n) max_n = (size_t)lv.n;
+    }
+    if (e->cfg.blur_filter_size[l] > max_ks) max_ks = e->cfg.blur_filter_size[l];
+  }
+  const size_t px = (size_t)width * (size_t)height;
+  hipError_t he = hipMalloc(&e->d_gray, px);
+  if (he == hipSuccess) he = hipMalloc(&e->d_depth, px * sizeof(double));
+  if (he == hipSuccess) he = hipMalloc(&e->d_depth16, px * sizeof(uint16_t));
+  if (he == hipSuccess && max_ks > 0) {
+    he = hipMalloc(&e->d_tmp, sizeof(double) * (max_n ? max_n : 1));
+    if (he == hipSuccess) he = hipMalloc(&e->d_blur_kernel, sizeof(double) * (size_t)max_ks * PHOVO_MAX_LEVELS);
+    if (he == hipSuccess) {
+      // getGaussianKernel(k, sigma = 3, CV_64F): exp(-0.5/sigma^2 * (i-(k-1)/2)^2), normalised.
+      e->blur_kernel_stride = max_ks;
+      std::vector<double> kern((size_t)max_ks * PHOVO_MAX_LEVELS, 0.0);
+      for (int l = 0; l < e->cfg.num_levels; l++) {
+        const int ks = e->cfg.blur_filter_size[l];
+        if (ks <= 0) continue;
+        const double sigma = 3.0, scale2x = -0.5 / (sigma * sigma);
+        double sum = 0;
+        double *kk = kern.data() + (size_t)l * max_ks;
+        for (int i = 0; i < ks; i++) {
+          const double x = i - (ks - 1) * 0.5;
+          const double t = std::exp(scale2x * x * x);
+          kk[i] = t; sum += t;
+        }
+        sum = 1. / sum;
+        for (int i = 0; i < ks; i++) kk[i] *= sum;
+      }
+      he = hipMemcpy(e->d_blur_kernel, kern.data(), sizeof(double) * kern.size(), hipMemcpyHostToDevice);
+    }
+  }
+  if (he != hipSuccess) { free_pool(e); return fail(PHOVO_E_HIP, std::string("hipMalloc(staging): ") + hipGetErrorString(he)); }
+  e->n_frames = n_frames; e->width = width; e->height = height;
+  PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
+  return PHOVO_OK;
+}
+
+int phovo_engine_level_size(const phovo_engine *e, int level, int *width, int *height)
+{
+  if (!e || !width || !height) return fail(PHOVO_E_INVALID_ARGUMENT, "level_size: null");
+  if (level < 0 || level >= e->cfg.num_levels) return fail(PHOVO_E_INVALID_ARGUMENT, "level out of range");
+  if (e->n_frames == 0) return fail(PHOVO_E_NOT_READY, "no frame pool reserved");
+  *width = e->levels[level].w;
+  *height = e->levels[level].h;
+  return PHOVO_OK;
+}
+
+int phovo_engine_level_is_stored(const phovo_engine *e, int level)
+{
+  if (!e || level < 0 || level >= e->cfg.num_levels || e->n_frames == 0) return 0;
+  return e->levels[level].stored ? 1 : 0;
+}
+
+static int upload_common(phovo_engine *e, int frame, int roles, const uint8_t *intensity, size_t istride)
+{
+  if (!e || !intensity) return fail(PHOVO_E_INVALID_ARGUMENT, "upload_frame: null");
+  if (e->n_frames == 0) return fail(PHOVO_E_NOT_READY, "upload_frame: reserve_frames first");
+  if (frame < 0 || frame >= e->n_frames) return fail(PHOVO_E_INVALID_ARGUMENT, "upload_frame: frame index out of range");
+  if ((roles & PHOVO_ROLE_BOTH) == 0) return fail(PHOVO_E_INVALID_ARGUMENT, "upload_frame: roles empty");
+  PHOVO_HIP_CHECK(hipSetDevice(e->device));
+  return copy_rows_to_device(e->d_gray, intensity, istride, (size_t)e->width, e->height, e->stream);
+}
+
+int phovo_engine_upload_frame(phovo_engine *e, int frame, int roles,
+                              const uint8_t *intensity, size_t intensity_stride,
+                              const double *depth, size_t depth_stride)
+{
+  int st = upload_common(e, frame, roles, intensity, intensity_stride);
+  if (st != PHOVO_OK) return st;
+  if (roles & PHOVO_ROLE_SOURCE) {
+    if (!depth) return fail(PHOVO_E_INVALID_ARGUMENT, "upload_frame: a source frame needs depth");
+    st = copy_rows_to_device(e->d_depth, depth, depth_stride, sizeof(double) * (size_t)e->width, e->height, e->stream);
+    if (st != PHOVO_OK) return st;
+  }
+  st = build_frame_pyramids(e, frame, roles);
+  if (st != PHOVO_OK) return st;
+  PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));     // the caller's buffers may be reused on return
+  return PHOVO_OK;
+}
+
+int phovo_engine_upload_frame_u16(phovo_engine *e, int frame, int roles,
+                                  const uint8_t *intensity, size_t intensity_stride,
+                                  const uint16_t *depth, size_t depth_stride, double depth_scale)
+{
+  int st = upload_common(e, frame, roles, intensity, intensity_stride);
+  if (st != PHOVO_OK) return st;
+  if (roles & PHOVO_ROLE_SOURCE) {
+    if (!depth) return fail(PHOVO_E_INVALID_ARGUMENT, "upload_frame_u16: a source frame needs depth");
+    st = copy_rows_to_device(e->d_depth16, depth, depth_stride, sizeof(uint16_t) * (size_t)e->width, e->height, e->stream);
+    if (st != PHOVO_OK) return st;
+    PHOVO_HIP_CHECK(pyr_depth_u16_to_f64(e->d_depth16, e->width * e->height, depth_scale, e->d_depth, e->stream));
+  }
+  st = build_frame_pyramids(e, frame, roles);
+  if (st != PHOVO_OK) return st;
+  PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
+  return PHOVO_OK;
+}
+
+static int plane_access_check(const phovo_engine *e, int frame, int level)
+{
+  if (!e) return fail(PHOVO_E_INVALID_ARGUMENT, "level planes: null engine");
+  if (e->n_frames == 0) return fail(PHOVO_E_NOT_READY, "level planes: reserve_frames first");
+  if (frame < 0 || frame >= e->n_frames) return fail(PHOVO_E_INVALID_ARGUMENT, "level planes: frame index out of range");
+  if (level < 0 || level >= e->cfg.num_levels) return fail(PHOVO_E_INVALID_ARGUMENT, "level planes: level out of range");
+  if (!e->levels[level].stored) return fail(PHOVO_E_NOT_READY, "level planes: level is not resident (max_num_iterations == 0 and build_all_levels off)");
+  return PHOVO_OK;
+}
+
+int phovo_engine_set_level_planes(phovo_engine *e, int frame, int level,
+                                  const double *intensity, const double *depth,
+                                  const double *grad_x, const double *grad_y)
+{
+  const int st = plane_access_check(e, frame, level);
+  if (st != PHOVO_OK) return st;
+  PHOVO_HIP_CHECK(hipSetDevice(e->device));
+  const LevelPool &lv = e->levels[level];
+  double *base = lv.planes + (size_t)frame * PLANES_PER_FRAME * (size_t)lv.n;
+  const double *srcs[4] = {intensity, depth, grad_x, grad_y};
+  for (int p = 0; p < 4; p++) {
+    if (!srcs[p]) continue;
+    PHOVO_HIP_CHECK(hipMemcpyAsync(base + (size_t)p * lv.n, srcs[p], sizeof(double) * (size_t)lv.n,
+                                   hipMemcpyHostToDevice, e->stream));
+  }
+  PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
+  return PHOVO_OK;
+}
+
+int phovo_engine_get_level_planes(const phovo_engine *e, int frame, int level,
+                                  double *intensity, double *depth, double *grad_x, double *grad_y)
+{
+  const int st = plane_access_check(e, frame, level);
+  if (st != PHOVO_OK) return st;
+  PHOVO_HIP_CHECK(hipSetDevice(e->device));
+  const LevelPool &lv = e->levels[level];
+  const double *base = lv.planes + (size_t)frame * PLANES_PER_FRAME * (size_t)lv.n;
+  double *dsts[4] = {intensity, depth, grad_x, grad_y};
+  PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
+  for (int p = 0; p < 4; p++) {
+    if (!dsts[p]) continue;
+    PHOVO_HIP_CHECK(hipMemcpy(dsts[p], base + (size_t)p * lv.n, sizeof(double) * (size_t)lv.n, hipMemcpyDeviceToHost));
+  }
+  return PHOVO_OK;
+}
+
+int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_frames,
+                               const int *target_frames, const double *init_states)
+{
+  if (!e || !source_frames || !target_frames) return fail(PHOVO_E_INVALID_ARGUMENT, "align: null");
+  if (n_pairs < 0) return fail(PHOVO_E_INVALID_ARGUMENT, "align: n_pairs < 0");
+  if (e->n_frames == 0) return fail(PHOVO_E_NOT_READY, "align: no frames uploaded");
+  if (!e->have_K) return fail(PHOVO_E_NOT_READY, "align: SetIntrinsicMatrix has not been called");
+  for (int i = 0; i < n_pairs; i++) {
+    if (source_frames[i] < 0 || source_frames[i] >= e->n_frames || target_frames[i] < 0 || target_frames[i] >= e->n_frames)
+      return fail(PHOVO_E_INVALID_ARGUMENT, "align: frame index out of range");
+  }
+  e->last_pairs = n_pairs;
+  e->have_timing = false;
+  for (bool &b : e->level_launched) b = false;
+  if (n_pairs == 0) return PHOVO_OK;
+  PHOVO_HIP_CHECK(hipSetDevice(e->device));
+  int st = ensure_pairs(e, n_pairs);
+  if (st != PHOVO_OK) return st;
+
+  // every active level must be launchable before anything is enqueued
+  size_t owner_need = 0;
+  for (int l = 0; l < e->cfg.num_levels; l++) {
+    if (e->cfg.max_num_iterations[l] <= 0) continue;
+    const LevelPool &lv = e->levels[l];
+    if (!lv.stored) return fail(PHOVO_E_NOT_READY, "align: an active level is not resident");
+    if (!lv.plan_ok) return fail(PHOVO_E_SHAPE, "align: pyramid level too large for the device path (in-bounds mask exceeds LDS)");
+    if (!lv.plan.owner_in_lds) {
+      const size_t need = (size_t)n_pairs * (size_t)lv.n;
+      if (need > owner_need) owner_need = need;
+    }
+  }
+  if (owner_need > e->owner_capacity) {
+    if (e->d_owner) { PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream)); (void)hipFree(e->d_owner); e->d_owner = nullptr; e->owner_capacity = 0; }
+    PHOVO_HIP_CHECK(hipMalloc(&e->d_owner, sizeof(int) * owner_need));
+    e->owner_capacity = owner_need;
+    // -1 everywhere once; pass 2 of the kernel restores -1 after every iteration
+    PHOVO_HIP_CHECK(fill_i32(e->d_owner, owner_need, -1, e->stream));
+  }
+
+  PHOVO_HIP_CHECK(hipMemcpyAsync(e->d_src, source_frames, sizeof(int) * (size_t)n_pairs, hipMemcpyHostToDevice, e->stream));
+  PHOVO_HIP_CHECK(hipMemcpyAsync(e->d_tgt, target_frames, sizeof(int) * (size_t)n_pairs, hipMemcpyHostToDevice, e->stream));
+  if (init_states)                                                                   // SetInitialStateVector  :494
+    PHOVO_HIP_CHECK(hipMemcpyAsync(e->d_states, init_states, sizeof(double) * 6 * (size_t)n_pairs, hipMemcpyHostToDevice, e->stream));
+  else
+    PHOVO_HIP_CHECK(hipMemsetAsync(e->d_states, 0, sizeof(double) * 6 * (size_t)n_pairs, e->stream));
+  PHOVO_HIP_CHECK(hipMemsetAsync(e->d_reports, 0, sizeof(phovo_pair_report) * (size_t)n_pairs, e->stream));
+
+  for (int l = e->cfg.num_levels - 1; l >= 0; l--) {                                 // coarse to fine  :502-503
+    if (e->cfg.max_num_iterations[l] <= 0) continue;                                 // :526 (nothing observable happens)
+    const LevelPool &lv = e->levels[l];
+    GNLevelArgs a{};
+    a.w = lv.w; a.h = lv.h; a.n = lv.n; a.level = l;
+    a.max_iter = e->cfg.max_num_iterations[l];
+    a.n_chunks = (lv.n + 63) / 64;
+    a.lambda = e->cfg.lambda_optimization_step[l];
+    a.min_grad_norm = e->cfg.min_gradient_norm[l];
+    const double scaleFactor = 1.0 / std::pow(2, l);                                 // :203
+    a.fx = e->K[0] * scaleFactor; a.fy = e->K[4] * scaleFactor;                      // :204-207
+    a.ox = e->K[2] * scaleFactor; a.oy = e->K[5] * scaleFactor;
+    a.ifx = 1.f / a.fx; a.ify = 1.f / a.fy;                                          // :208-209
+    a.min_depth = e->min_depth; a.max_depth = e->max_depth;
+    a.planes = lv.planes;
+    a.src = e->d_src; a.tgt = e->d_tgt;
+    a.states = e->d_states; a.reports = e->d_reports;
+    a.g_owner = e->d_owner;
+    PHOVO_HIP_CHECK(hipEventRecord(e->ev_start[l], e->stream));
+    PHOVO_HIP_CHECK(gn_launch_level(a, lv.plan, n_pairs, e->stream));
+    PHOVO_HIP_CHECK(hipEventRecord(e->ev_stop[l], e->stream));
+    e->level_launched[l] = true;
+  }
+  e->have_timing = true;
+  return PHOVO_OK;
+}
+
+int phovo_engine_synchronize(phovo_engine *e)
+{
+  if (!e) return fail(PHOVO_E_INVALID_ARGUMENT, "synchronize: null");
+  PHOVO_HIP_CHECK(hipSetDevice(e->device));
+  PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
+  return PHOVO_OK;
+}
+
+int phovo_engine_fetch_results(phovo_engine *e, int n_pairs, double *out_states, phovo_pair_report *reports)
+{
+  if (!e) return fail(PHOVO_E_INVALID_ARGUMENT, "fetch_results: null");
+  if (n_pairs != e->last_pairs) return fail(PHOVO_E_INVALID_ARGUMENT, "fetch_results: n_pairs differs from the last enqueue");
+  if (n_pairs == 0) return PHOVO_OK;
+  PHOVO_HIP_CHECK(hipSetDevice(e->device));
+  PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
+  if (out_states)
+    PHOVO_HIP_CHECK(hipMemcpy(out_states, e->d_states, sizeof(double) * 6 * (size_t)n_pairs, hipMemcpyDeviceToHost));
+  if (reports) {
+    PHOVO_HIP_CHECK(hipMemcpy(reports, e->d_reports, sizeof(phovo_pair_report) * (size_t)n_pairs, hipMemcpyDeviceToHost));
+    // Levels with max_num_iterations == 0 still run the loop body once in the reference (:510,547-549).
+    for (int i = 0; i < n_pairs; i++)
+      for (int l = 0; l < e->cfg.num_levels; l++)
+        if (e->cfg.max_num_iterations[l] <= 0) reports[i].iterations[l] = 1;
+  }
+  return PHOVO_OK;
+}
+
+int phovo_engine_results_device_ptr(phovo_engine *e, void **states)
+{
+  if (!e || !states) return fail(PHOVO_E_INVALID_ARGUMENT, "results_device_ptr: null");
+  *states = e->d_states;
+  return PHOVO_OK;
+}
+
+int phovo_engine_align_pairs(phovo_engine *e, int n_pairs, const int *source_frames,
+                             const int *target_frames, const double *init_states,
+                             double *out_states, phovo_pair_report *reports)
+{
+  int st = phovo_engine_enqueue_align(e, n_pairs, source_frames, target_frames, init_states);
+  if (st != PHOVO_OK) return st;
+  return phovo_engine_fetch_results(e, n_pairs, out_states, reports);
+}
+
+int phovo_engine_last_align_ms(const phovo_engine *e, double *total_ms, double level_ms[PHOVO_MAX_LEVELS])
+{
+  if (!e) return fail(PHOVO_E_INVALID_ARGUMENT, "last_align_ms: null");
+  if (!e->have_timing) return fail(PHOVO_E_NOT_READY, "last_align_ms: nothing has been enqueued");
+  PHOVO_HIP_CHECK(hipSetDevice(e->device));
+  PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
+  double total = 0;
+  for (int l = 0; l < PHOVO_MAX_LEVELS; l++) {
+    double ms = 0;
+    if (e->level_launched[l]) {
+      float f = 0;
+      PHOVO_HIP_CHECK(hipEventElapsedTime(&f, e->ev_start[l], e->ev_stop[l]));
+      ms = f;
+    }
+    if (level_ms) level_ms[l] = ms;
+    total += ms;
+  }
+  if (total_ms) *total_ms = total;
+  return PHOVO_OK;
+}
+
+int phovo_engine_level_launch_info(const phovo_engine *e, int level, int *threads, int *lds_bytes,
+                                   int *owner_in_lds, int *source_in_lds)
+{
+  if (!e) return fail(PHOVO_E_INVALID_ARGUMENT, "level_launch_info: null");
+  if (level < 0 || level >= e->cfg.num_levels) return fail(PHOVO_E_INVALID_ARGUMENT, "level out of range");
+  if (e->n_frames == 0) return fail(PHOVO_E_NOT_READY, "no frame pool reserved");
+  const LevelPool &lv = e->levels[level];
+  if (!lv.plan_ok) return fail(PHOVO_E_SHAPE, "level too large for the device path");
+  if (threads) *threads = lv.plan.threads;
+  if (lds_bytes) *lds_bytes = lv.plan.lds_bytes;
+  if (owner_in_lds) *owner_in_lds = lv.plan.owner_in_lds ? 1 : 0;
+  if (source_in_lds) *source_in_lds = lv.plan.source_in_lds ? 1 : 0;
+  return PHOVO_OK;
+}
+
+}  // extern "C"
+
+/* ------------------------------------------------------------------ single pair ------------- */
+
+struct phovo_odometry {
+  phovo_engine *engine = nullptr;
+  bool have_source = false, have_target = false, optimized = false;
+  double init_state[6] = {0, 0, 0, 0, 0, 0};
+  double state[6] = {0, 0, 0, 0, 0, 0};          // m_StateVector.setZero()  :432
+  phovo_pair_report report{};
+};
+
+namespace {
+
+int odometry_set_frame(phovo_odometry *o, int slot, int role, const uint8_t *intensity, size_t istride,
+                       const double *depth, size_t dstride, int width, int height)
+{
+  if (!o || !intensity) return fail(PHOVO_E_INVALID_ARGUMENT, "Set*Frame: null");
+  if (width < 1 || height < 1) return fail(PHOVO_E_INVALID_ARGUMENT, "Set*Frame: empty image");
+  phovo_engine *e = o->engine;
+  if (e->n_frames == 0 || e->width != width || e->height != height) {
+    const int st = phovo_engine_reserve_frames(e, 2, width, height);
+    if (st != PHOVO_OK) return st;
+    o->have_source = o->have_target = false;
+  }
+  const int st = phovo_engine_upload_frame(e, slot, role, intensity, istride, depth, dstride);
+  if (st != PHOVO_OK) return st;
+  if (slot == 0) o->have_source = true; else o->have_target = true;
+  o->optimized = false;
+  return PHOVO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int phovo_odometry_create(int device, phovo_odometry **out)
+{
+  if (!out) return fail(PHOVO_E_INVALID_ARGUMENT, "phovo_odometry_create: null");
+  *out = nullptr;
+  phovo_engine *e = nullptr;
+  const int st = phovo_engine_create(device, &e);
+  if (st != PHOVO_OK) return st;
+  phovo_odometry *o = new (std::nothrow) phovo_odometry();
+  if (!o) { phovo_engine_destroy(e); return fail(PHOVO_E_INVALID_ARGUMENT, "out of host memory"); }
+  o->engine = e;
+  *out = o;
+  return PHOVO_OK;
+}
+
+int phovo_odometry_destroy(phovo_odometry *o)
+{
+  if (!o) return PHOVO_OK;
+  phovo_engine_destroy(o->engine);
+  delete o;
+  return PHOVO_OK;
+}
+
+int phovo_odometry_set_config(phovo_odometry *o, const phovo_config *cfg)
+{
+  if (!o) return fail(PHOVO_E_INVALID_ARGUMENT, "set_config: null");
+  const int st = phovo_engine_set_config(o->engine, cfg);
+  if (st == PHOVO_OK) o->have_source = o->have_target = o->optimized = false;
+  return st;
+}
+
+int phovo_odometry_read_configuration_file(phovo_odometry *o, const char *path)
+{
+  if (!o) return fail(PHOVO_E_INVALID_ARGUMENT, "ReadConfigurationFile: null");
+  phovo_config c;
+  const int st = read_config_file(path, &c);
+  if (st != PHOVO_OK) return st;
+  return phovo_odometry_set_config(o, &c);
+}
+
+int phovo_odometry_set_min_depth(phovo_odometry *o, double v)
+{
+  if (!o) return fail(PHOVO_E_INVALID_ARGUMENT, "SetMinDepth: null");
+  o->engine->min_depth = v;
+  return PHOVO_OK;
+}
+
+int phovo_odometry_set_max_depth(phovo_odometry *o, double v)
+{
+  if (!o) return fail(PHOVO_E_INVALID_ARGUMENT, "SetMaxDepth: null");
+  o->engine->max_depth = v;
+  return PHOVO_OK;
+}
+
+int phovo_odometry_set_intrinsic_matrix(phovo_odometry *o, const double k[9])
+{
+  if (!o) return fail(PHOVO_E_INVALID_ARGUMENT, "SetIntrinsicMatrix: null");
+  return phovo_engine_set_intrinsic_matrix(o->engine, k);
+}
+
+int phovo_odometry_set_source_frame(phovo_odometry *o, const uint8_t *intensity, size_t istride,
+                                    const double *depth, size_t dstride, int width, int height)
+{
+  if (!depth) return fail(PHOVO_E_INVALID_ARGUMENT, "SetSourceFrame: depth is required");
+  return odometry_set_frame(o, 0, PHOVO_ROLE_SOURCE, intensity, istride, depth, dstride, width, height);
+}
+
+int phovo_odometry_set_target_frame(phovo_odometry *o, const uint8_t *intensity, size_t istride,
+                                    const double *depth, size_t dstride, int width, int height)
+{
+  (void)depth; (void)dstride;                      // "Depth image is ignored"  :478
+  return odometry_set_frame(o, 1, PHOVO_ROLE_TARGET, intensity, istride, nullptr, 0, width, height);
+}
+
+int phovo_odometry_set_initial_state_vector(phovo_odometry *o, const double state[6])
+{
+  if (!o || !state) return fail(PHOVO_E_INVALID_ARGUMENT, "SetInitialStateVector: null");
+  std::memcpy(o->init_state, state, sizeof(o->init_state));
+  std::memcpy(o->state, state, sizeof(o->state));   // m_StateVector = initialStateVector  :496
+  return PHOVO_OK;
+}
+
+int phovo_odometry_optimize(phovo_odometry *o)
+{
+  if (!o) return fail(PHOVO_E_INVALID_ARGUMENT, "Optimize: null");
+  if (!o->have_source || !o->have_target)
+    return fail(PHOVO_E_NOT_READY, "Optimize: SetSourceFrame and SetTargetFrame must be called first");
+  const int src = 0, tgt = 1;
+  // Like the reference, Optimize() starts from the CURRENT state vector (:539 updates m_StateVector in place).
+  const int st = phovo_engine_align_pairs(o->engine, 1, &src, &tgt, o->state, o->state, &o->report);
+  if (st != PHOVO_OK) return st;
+  o->optimized = true;
+  return PHOVO_OK;
+}
+
+int phovo_odometry_get_optimal_state_vector(const phovo_odometry *o, double state[6])
+{
+  if (!o || !state) return fail(PHOVO_E_INVALID_ARGUMENT, "GetOptimalStateVector: null");
+  std::memcpy(state, o->state, sizeof(o->state));
+  return PHOVO_OK;
+}
+
+int phovo_odometry_get_optimal_rigid_transformation_matrix(const phovo_odometry *o, double rt[16])
+{
+  if (!o || !rt) return fail(PHOVO_E_INVALID_ARGUMENT, "GetOptimalRigidTransformationMatrix: null");
+  return phovo_eigen_pose(o->state, rt);            // :572-578
+}
+
+int phovo_odometry_get_report(const phovo_odometry *o, phovo_pair_report *report)
+{
+  if (!o || !report) return fail(PHOVO_E_INVALID_ARGUMENT, "get_report: null");
+  if (!o->optimized) return fail(PHOVO_E_NOT_READY, "get_report: Optimize has not run");
+  *report = o->report;
+  return PHOVO_OK;
+}
+
+int phovo_odometry_last_optimize_ms(const phovo_odometry *o, double *ms)
+{
+  if (!o || !ms) return fail(PHOVO_E_INVALID_ARGUMENT, "last_optimize_ms: null");
+  if (!o->optimized) return fail(PHOVO_E_NOT_READY, "last_optimize_ms: Optimize has not run");
+  return phovo_engine_last_align_ms(o->engine, ms, nullptr);
+}
+
+}  // extern "C"

@@ -1,0 +1,69 @@
+// Internal declarations shared by the host engine and the HIP kernels (not part of the ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+
+#include "phovo_hip.h"
+
+namespace phovo_hip {
+
+// Planes of one frame at one level, in pool order.
+enum Plane { PLANE_I = 0, PLANE_D = 1, PLANE_GX = 2, PLANE_GY = 3, PLANES_PER_FRAME = 4 };
+
+// Everything one Gauss-Newton level launch needs (passed by value as the kernel argument,
+// so the scalars land in SGPRs).
+struct GNLevelArgs {
+  int w, h, n;              // level size, n = w*h
+  int level;
+  int max_iter;             // max_num_iterations[level] (> 0)
+  int n_chunks;             // ceil(n / 64)
+  double lambda;            // lambda_optimization_step[level]
+  double min_grad_norm;     // min_gradient_norm[level]
+  double fx, fy, ox, oy, ifx, ify;   // level-scaled intrinsics (...Analytic.h:203-209)
+  double min_depth, max_depth;
+  const double *planes;     // pool of this level: [frame][PLANES_PER_FRAME][n]
+  const int *src;           // [pairs] source frame of each pair
+  const int *tgt;           // [pairs] target frame of each pair
+  double *states;           // [pairs][6] in: initial / previous level, out: updated
+  phovo_pair_report *reports;   // [pairs]
+  int *g_owner;             // [pairs][n] owner map in global memory (only when it does not fit LDS)
+};
+
+struct GNLaunchPlan {
+  int threads;              // workgroup size
+  int lds_bytes;            // dynamic LDS
+  bool owner_in_lds;
+  bool source_in_lds;
+};
+
+// Chooses the launch geometry for a level of n pixels.  Returns false if the level cannot be
+// handled (inbound-mask does not fit LDS).
+bool gn_plan_level(int n, GNLaunchPlan *plan);
+hipError_t gn_launch_level(const GNLevelArgs &args, const GNLaunchPlan &plan, int n_pairs,
+                           hipStream_t stream);
+hipError_t gn_prepare_kernels();   // raises the dynamic-LDS limit of every instantiation
+
+// Pyramid producers (SetSourceFrame / SetTargetFrame, ...Analytic.h:466-491).
+hipError_t pyr_intensity_level(const uint8_t *gray, int w, int h, int level, int lw, int lh,
+                               double *dst, hipStream_t stream);
+hipError_t pyr_depth_level(const double *depth, int w, int h, int level, int lw, int lh,
+                           double *dst, hipStream_t stream);
+hipError_t pyr_depth_u16_to_f64(const uint16_t *src, int n, double scale, double *dst,
+                                hipStream_t stream);
+hipError_t pyr_scharr(const double *img, int w, int h, double scale, double *gx, double *gy,
+                      hipStream_t stream);
+hipError_t pyr_gaussian_blur(double *img, double *tmp, int w, int h, int ksize,
+                             const double *d_kernel, hipStream_t stream);
+hipError_t fill_i32(int *dst, size_t n, int value, hipStream_t stream);
+
+// Error plumbing
+void set_last_error(const std::string &msg);
+int fail(int status, const std::string &msg);
+
+// OpenCV-FileStorage-dialect reader (yml_config.cpp)
+int read_config_file(const char *path, phovo_config *cfg);
+
+}  // namespace phovo_hip

@@ -1,0 +1,201 @@
+// Device pyramid producers: what SetSourceFrame / SetTargetFrame do through OpenCV
+// (phovo/include/CPhotoconsistencyOdometryAnalytic.h:115-189,466-491):
+//   convertTo(fp64, 1./255), cv::resize(level 0 -> level L, INTER_LINEAR), optional GaussianBlur x2,
+//   cv::Scharr dx/dy with the per-level scale.
+// The arithmetic follows oracle/phovo_oracle.c operation for operation (floating-point contraction
+// is switched off in this file) so that device pyramids are BIT-IDENTICAL to the oracle's; whether
+// they are bit-identical to OpenCV's cannot be checked in this image (OpenCV is absent) -- callers
+// that need OpenCV's exact planes can hand them over with phovo_engine_set_level_planes().
+// These kernels are HBM-bound streaming kernels outside the reference's timed region
+// (apps/PhotoconsistencyFrameAlignment/PhotoconsistencyFrameAlignment.cpp:94-101).
+
+#include <hip/hip_runtime.h>
+
+#include "phovo_internal.hpp"
+
+#pragma clang fp contract(off)
+
+namespace phovo_hip {
+
+namespace {
+
+__device__ __forceinline__ double load_px(const uint8_t *src, size_t i)
+{
+  return (double)src[i] * (1. / 255);          // convertTo(..., 1./255)  :471,484
+}
+__device__ __forceinline__ double load_px(const double *src, size_t i) { return src[i]; }
+
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+  if (len == 1) return 0;
+  while (p < 0 || p >= len) {
+    if (p < 0) p = -p;
+    else p = 2 * len - 2 - p;
+  }
+  return p;
+}
+
+// cv::resize by 2^-level from level 0.  level 1: 2x2 area mean (((a+b)+c)+d)*0.25;
+// level >= 2: bilinear with the two central taps, weights 0.5 -- rows first, then columns.
+template <typename SrcT>
+__global__ __launch_bounds__(256) void k_resize_level(const SrcT *src, int w, int h, int level,
+                                                      int lw, int lh, double *dst)
+{
+  const int dx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int dy = blockIdx.y;
+  if (dx >= lw || dy >= lh) return;
+  double out;
+  if (level == 0) {
+    out = load_px(src, (size_t)dy * w + dx);
+  } else if (level == 1) {
+    const int sx = dx * 2, sy = dy * 2;
+    if (sx + 1 < w && sy + 1 < h) {
+      const double a = load_px(src, (size_t)sy * w + sx), b = load_px(src, (size_t)sy * w + sx + 1);
+      const double c = load_px(src, (size_t)(sy + 1) * w + sx), d = load_px(src, (size_t)(sy + 1) * w + sx + 1);
+      out = (((a + b) + c) + d) * 0.25;
+    } else {
+      double sum = 0; int count = 0;
+      for (int yy = 0; yy < 2; yy++) {
+        if (sy + yy >= h) break;
+        for (int xx = 0; xx < 2; xx++) {
+          if (sx + xx >= w) break;
+          sum += load_px(src, (size_t)(sy + yy) * w + sx + xx);
+          count++;
+        }
+      }
+      out = count ? sum / count : 0.0;
+    }
+  } else {
+    const int s = 1 << level, half = s / 2 - 1;
+    int sy = dy * s + half; double wy1 = 0.5;
+    if (sy >= h - 1) { sy = h - 1; wy1 = 0.0; }
+    int sx = dx * s + half; double wx1 = 0.5;
+    if (sx >= w - 1) { sx = w - 1; wx1 = 0.0; }
+    double top, bot;
+    if (wx1 != 0.0) top = load_px(src, (size_t)sy * w + sx) * 0.5 + load_px(src, (size_t)sy * w + sx + 1) * 0.5;
+    else top = load_px(src, (size_t)sy * w + sx) * 1.0;
+    if (wy1 != 0.0) {
+      if (wx1 != 0.0)
+        bot = load_px(src, (size_t)(sy + 1) * w + sx) * 0.5 + load_px(src, (size_t)(sy + 1) * w + sx + 1) * 0.5;
+      else
+        bot = load_px(src, (size_t)(sy + 1) * w + sx) * 1.0;
+      out = top * 0.5 + bot * 0.5;
+    } else {
+      out = top * 1.0 + top * 0.0;
+    }
+  }
+  dst[(size_t)dy * lw + dx] = out;
+}
+
+__global__ __launch_bounds__(256) void k_u16_to_f64(const uint16_t *src, int n, double scale, double *dst)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (double)src[i] * scale;
+}
+
+// cv::Scharr (1,0) and (0,1), scale on the smoothing kernel, BORDER_REFLECT_101  (:181-187).
+__global__ __launch_bounds__(256) void k_scharr(const double *img, int w, int h, double scale,
+                                                double *gx, double *gy)
+{
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x >= w || y >= h) return;
+  const double k3 = 3.0 * scale, k10 = 10.0 * scale;
+  const int xl = reflect101(x - 1, w), xr = reflect101(x + 1, w);
+  const int yu = reflect101(y - 1, h), yd = reflect101(y + 1, h);
+  const int rows[3] = {yu, y, yd};
+  double tx[3], ty[3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    const double *row = img + (size_t)rows[j] * w;
+    const double a = row[xl], b = row[x], c = row[xr];
+    tx[j] = ((-1.0 * a) + (0.0 * b)) + (1.0 * c);
+    ty[j] = ((k3 * a) + (k10 * b)) + (k3 * c);
+  }
+  gx[(size_t)y * w + x] = (k10 * tx[1]) + (k3 * (tx[2] + tx[0]));
+  gy[(size_t)y * w + x] = 0.0 + 1.0 * (ty[2] - ty[0]);
+}
+
+// One separable Gaussian pass (rows, then columns) -- cv::GaussianBlur(k x k, sigma 3)  (:146-147).
+__global__ __launch_bounds__(256) void k_blur_rows(const double *img, int w, int h, int ksize,
+                                                   const double *kern, double *tmp)
+{
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x >= w || y >= h) return;
+  const int r = ksize / 2;
+  const double *row = img + (size_t)y * w;
+  double s0 = kern[0] * row[reflect101(x - r, w)];
+  for (int k = 1; k < ksize; k++) s0 += kern[k] * row[reflect101(x - r + k, w)];
+  tmp[(size_t)y * w + x] = s0;
+}
+
+__global__ __launch_bounds__(256) void k_blur_cols(const double *tmp, int w, int h, int ksize,
+                                                   const double *kern, double *img)
+{
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x >= w || y >= h) return;
+  const int r = ksize / 2;
+  double s0 = kern[r] * tmp[(size_t)y * w + x];
+  for (int k = 1; k <= r; k++)
+    s0 += kern[r + k] * (tmp[(size_t)reflect101(y + k, h) * w + x] + tmp[(size_t)reflect101(y - k, h) * w + x]);
+  img[(size_t)y * w + x] = s0;
+}
+
+__global__ __launch_bounds__(256) void k_fill_i32(int *dst, size_t n, int value)
+{
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dst[i] = value;
+}
+
+inline dim3 grid2d(int w, int h) { return dim3((unsigned)((w + 255) / 256), (unsigned)h); }
+
+}  // namespace
+
+hipError_t pyr_intensity_level(const uint8_t *gray, int w, int h, int level, int lw, int lh,
+                               double *dst, hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_resize_level<uint8_t>, grid2d(lw, lh), dim3(256), 0, stream, gray, w, h, level, lw, lh, dst);
+  return hipGetLastError();
+}
+
+hipError_t pyr_depth_level(const double *depth, int w, int h, int level, int lw, int lh,
+                           double *dst, hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_resize_level<double>, grid2d(lw, lh), dim3(256), 0, stream, depth, w, h, level, lw, lh, dst);
+  return hipGetLastError();
+}
+
+hipError_t pyr_depth_u16_to_f64(const uint16_t *src, int n, double scale, double *dst, hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_u16_to_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, n, scale, dst);
+  return hipGetLastError();
+}
+
+hipError_t pyr_scharr(const double *img, int w, int h, double scale, double *gx, double *gy,
+                      hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_scharr, grid2d(w, h), dim3(256), 0, stream, img, w, h, scale, gx, gy);
+  return hipGetLastError();
+}
+
+hipError_t pyr_gaussian_blur(double *img, double *tmp, int w, int h, int ksize,
+                             const double *d_kernel, hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_blur_rows, grid2d(w, h), dim3(256), 0, stream, img, w, h, ksize, d_kernel, tmp);
+  hipLaunchKernelGGL(k_blur_cols, grid2d(w, h), dim3(256), 0, stream, tmp, w, h, ksize, d_kernel, img);
+  return hipGetLastError();
+}
+
+hipError_t fill_i32(int *dst, size_t n, int value, hipStream_t stream)
+{
+  if (n == 0) return hipSuccess;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)blocks), dim3(256), 0, stream, dst, n, value);
+  return hipGetLastError();
+}
+
+}  // namespace phovo_hip

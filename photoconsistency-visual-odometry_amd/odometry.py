@@ -1,0 +1,278 @@
+"""Python host mirror of the reference's operator surface, over the C ABI.
+
+`CPhotoconsistencyOdometryAnalytic` has the method names, argument meaning and call order of
+phovo::Analytic::CPhotoconsistencyOdometryAnalytic<unsigned char,double>
+(phovo/include/CPhotoconsistencyOdometryAnalytic.h:428-607); `AlignmentEngine` is the batched form
+(one process per GPU, many independent frame pairs per launch).  Everything that computes runs in
+libphovo_hip.so on the GPU; numpy only carries buffers across the boundary.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import native
+from .native import check
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if a.ndim != 2:
+        raise ValueError("intensity image must be 2-D (gray)")
+    return a
+
+
+def _f64img(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if a.ndim != 2:
+        raise ValueError("depth image must be 2-D")
+    return a
+
+
+class CPhotoconsistencyOdometryAnalytic:
+    """One frame pair at a time; 1:1 with the reference class."""
+
+    def __init__(self, device=0):
+        self._lib = native.lib()
+        self._h = C.c_void_p()
+        check(self._lib.phovo_odometry_create(int(device), C.byref(self._h)), "phovo_odometry_create")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.phovo_odometry_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- configuration --------------------------------------------------------------------
+    def ReadConfigurationFile(self, fileName):
+        check(self._lib.phovo_odometry_read_configuration_file(self._h, str(fileName).encode()),
+              "ReadConfigurationFile")
+
+    def SetConfiguration(self, cfg):
+        check(self._lib.phovo_odometry_set_config(self._h, C.byref(cfg)), "SetConfiguration")
+
+    def SetMinDepth(self, minD):
+        check(self._lib.phovo_odometry_set_min_depth(self._h, float(minD)), "SetMinDepth")
+
+    def SetMaxDepth(self, maxD):
+        check(self._lib.phovo_odometry_set_max_depth(self._h, float(maxD)), "SetMaxDepth")
+
+    def SetIntrinsicMatrix(self, intrinsicMatrix):
+        k = np.ascontiguousarray(intrinsicMatrix, dtype=np.float64).reshape(9)
+        check(self._lib.phovo_odometry_set_intrinsic_matrix(self._h, k.ctypes.data_as(C.POINTER(C.c_double))),
+              "SetIntrinsicMatrix")
+
+    # -- frames ---------------------------------------------------------------------------
+    def SetSourceFrame(self, intensityImage, depthImage):
+        g, d = _u8(intensityImage), _f64img(depthImage)
+        if g.shape != d.shape:
+            raise ValueError("intensity and depth sizes differ")
+        h, w = g.shape
+        check(self._lib.phovo_odometry_set_source_frame(self._h, g.ctypes.data, g.strides[0],
+                                                        d.ctypes.data, d.strides[0], w, h), "SetSourceFrame")
+
+    def SetTargetFrame(self, intensityImage, depthImage=None):
+        g = _u8(intensityImage)
+        h, w = g.shape
+        d = _f64img(depthImage) if depthImage is not None else None
+        check(self._lib.phovo_odometry_set_target_frame(
+            self._h, g.ctypes.data, g.strides[0],
+            d.ctypes.data if d is not None else None, d.strides[0] if d is not None else 0, w, h),
+            "SetTargetFrame")
+
+    def SetInitialStateVector(self, initialStateVector):
+        s = np.ascontiguousarray(initialStateVector, dtype=np.float64).reshape(6)
+        check(self._lib.phovo_odometry_set_initial_state_vector(self._h, s.ctypes.data_as(C.POINTER(C.c_double))),
+              "SetInitialStateVector")
+
+    # -- optimisation ---------------------------------------------------------------------
+    def Optimize(self):
+        check(self._lib.phovo_odometry_optimize(self._h), "Optimize")
+
+    def GetOptimalStateVector(self):
+        s = np.zeros(6)
+        check(self._lib.phovo_odometry_get_optimal_state_vector(self._h, s.ctypes.data_as(C.POINTER(C.c_double))),
+              "GetOptimalStateVector")
+        return s
+
+    def GetOptimalRigidTransformationMatrix(self):
+        rt = np.zeros(16)
+        check(self._lib.phovo_odometry_get_optimal_rigid_transformation_matrix(
+            self._h, rt.ctypes.data_as(C.POINTER(C.c_double))), "GetOptimalRigidTransformationMatrix")
+        return rt.reshape(4, 4)
+
+    def GetReport(self):
+        rep = native.PairReport()
+        check(self._lib.phovo_odometry_get_report(self._h, C.byref(rep)), "GetReport")
+        return rep
+
+    def LastOptimizeMilliseconds(self):
+        ms = C.c_double()
+        check(self._lib.phovo_odometry_last_optimize_ms(self._h, C.byref(ms)), "LastOptimizeMilliseconds")
+        return ms.value
+
+
+class AlignmentEngine:
+    """Batched alignment: a pool of frames resident in HBM, pairs aligned one launch per level."""
+
+    def __init__(self, device=0):
+        self._lib = native.lib()
+        self._h = C.c_void_p()
+        check(self._lib.phovo_engine_create(int(device), C.byref(self._h)), "phovo_engine_create")
+        self.n_frames = 0
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.phovo_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_config(self, cfg):
+        check(self._lib.phovo_engine_set_config(self._h, C.byref(cfg)), "phovo_engine_set_config")
+
+    def read_configuration_file(self, path):
+        self.set_config(native.read_config_file(path))
+
+    def get_config(self):
+        cfg = native.Config()
+        check(self._lib.phovo_engine_get_config(self._h, C.byref(cfg)), "phovo_engine_get_config")
+        return cfg
+
+    def set_intrinsic_matrix(self, K):
+        k = np.ascontiguousarray(K, dtype=np.float64).reshape(9)
+        check(self._lib.phovo_engine_set_intrinsic_matrix(self._h, k.ctypes.data_as(C.POINTER(C.c_double))),
+              "phovo_engine_set_intrinsic_matrix")
+
+    def set_depth_range(self, min_depth, max_depth):
+        check(self._lib.phovo_engine_set_depth_range(self._h, float(min_depth), float(max_depth)),
+              "phovo_engine_set_depth_range")
+
+    def set_build_all_levels(self, on):
+        check(self._lib.phovo_engine_set_build_all_levels(self._h, int(bool(on))), "phovo_engine_set_build_all_levels")
+
+    def reserve_frames(self, n_frames, width, height):
+        check(self._lib.phovo_engine_reserve_frames(self._h, int(n_frames), int(width), int(height)),
+              "phovo_engine_reserve_frames")
+        self.n_frames = int(n_frames)
+
+    def level_size(self, level):
+        w, h = C.c_int(), C.c_int()
+        check(self._lib.phovo_engine_level_size(self._h, int(level), C.byref(w), C.byref(h)), "phovo_engine_level_size")
+        return w.value, h.value
+
+    def level_is_stored(self, level):
+        return bool(self._lib.phovo_engine_level_is_stored(self._h, int(level)))
+
+    def upload_frame(self, frame, gray, depth=None, roles=native.ROLE_BOTH):
+        g = _u8(gray)
+        d = _f64img(depth) if depth is not None else None
+        check(self._lib.phovo_engine_upload_frame(
+            self._h, int(frame), int(roles), g.ctypes.data, g.strides[0],
+            d.ctypes.data if d is not None else None, d.strides[0] if d is not None else 0),
+            "phovo_engine_upload_frame")
+
+    def upload_frame_u16(self, frame, gray, depth_u16, depth_scale, roles=native.ROLE_BOTH):
+        g = _u8(gray)
+        d = np.ascontiguousarray(depth_u16, dtype=np.uint16)
+        check(self._lib.phovo_engine_upload_frame_u16(
+            self._h, int(frame), int(roles), g.ctypes.data, g.strides[0], d.ctypes.data, d.strides[0],
+            float(depth_scale)), "phovo_engine_upload_frame_u16")
+
+    def set_level_planes(self, frame, level, intensity=None, depth=None, grad_x=None, grad_y=None):
+        arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+                for a in (intensity, depth, grad_x, grad_y)]
+        w, h = self.level_size(level)
+        for a in arrs:
+            if a is not None and a.size != w * h:
+                raise ValueError("plane size does not match the level")
+        ptrs = [a.ctypes.data if a is not None else None for a in arrs]
+        check(self._lib.phovo_engine_set_level_planes(self._h, int(frame), int(level), *ptrs),
+              "phovo_engine_set_level_planes")
+
+    def get_level_planes(self, frame, level):
+        w, h = self.level_size(level)
+        outs = [np.empty((h, w), dtype=np.float64) for _ in range(4)]
+        check(self._lib.phovo_engine_get_level_planes(self._h, int(frame), int(level),
+                                                      *[o.ctypes.data for o in outs]),
+              "phovo_engine_get_level_planes")
+        return tuple(outs)            # intensity, depth, grad_x, grad_y
+
+    @staticmethod
+    def _pairs(src, tgt):
+        s = np.ascontiguousarray(src, dtype=np.int32).reshape(-1)
+        t = np.ascontiguousarray(tgt, dtype=np.int32).reshape(-1)
+        if s.size != t.size:
+            raise ValueError("source / target lists differ in length")
+        return s, t
+
+    def align_pairs(self, src, tgt, init_states=None, want_reports=False):
+        s, t = self._pairs(src, tgt)
+        n = s.size
+        init = None if init_states is None else np.ascontiguousarray(init_states, dtype=np.float64).reshape(n, 6)
+        out = np.zeros((n, 6))
+        reps = (native.PairReport * max(n, 1))() if want_reports else None
+        ip = C.POINTER(C.c_int)
+        check(self._lib.phovo_engine_align_pairs(
+            self._h, n, s.ctypes.data_as(ip), t.ctypes.data_as(ip),
+            init.ctypes.data if init is not None else None, out.ctypes.data,
+            C.cast(reps, C.c_void_p) if reps is not None else None), "phovo_engine_align_pairs")
+        return (out, list(reps)[:n]) if want_reports else out
+
+    def enqueue_align(self, src, tgt, init_states=None):
+        s, t = self._pairs(src, tgt)
+        n = s.size
+        init = None if init_states is None else np.ascontiguousarray(init_states, dtype=np.float64).reshape(n, 6)
+        ip = C.POINTER(C.c_int)
+        check(self._lib.phovo_engine_enqueue_align(
+            self._h, n, s.ctypes.data_as(ip), t.ctypes.data_as(ip),
+            init.ctypes.data if init is not None else None), "phovo_engine_enqueue_align")
+        return n
+
+    def synchronize(self):
+        check(self._lib.phovo_engine_synchronize(self._h), "phovo_engine_synchronize")
+
+    def fetch_results(self, n, want_reports=False):
+        out = np.zeros((n, 6))
+        reps = (native.PairReport * max(n, 1))() if want_reports else None
+        check(self._lib.phovo_engine_fetch_results(
+            self._h, int(n), out.ctypes.data, C.cast(reps, C.c_void_p) if reps is not None else None),
+            "phovo_engine_fetch_results")
+        return (out, list(reps)[:n]) if want_reports else out
+
+    def results_device_ptr(self):
+        p = C.c_void_p()
+        check(self._lib.phovo_engine_results_device_ptr(self._h, C.byref(p)), "phovo_engine_results_device_ptr")
+        return p.value
+
+    def last_align_ms(self):
+        total = C.c_double()
+        per = (C.c_double * native.MAX_LEVELS)()
+        check(self._lib.phovo_engine_last_align_ms(self._h, C.byref(total), per), "phovo_engine_last_align_ms")
+        return total.value, list(per)
+
+    def level_launch_info(self, level):
+        t, l, o, s = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        check(self._lib.phovo_engine_level_launch_info(self._h, int(level), C.byref(t), C.byref(l),
+                                                       C.byref(o), C.byref(s)), "phovo_engine_level_launch_info")
+        return dict(threads=t.value, lds_bytes=l.value, owner_in_lds=bool(o.value), source_in_lds=bool(s.value))
