@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py -- frame-pair alignments per second of the analytic Gauss-Newton path on MI355X.
+
+One "step" = Optimize() for one batch of independent 640x480 frame pairs whose pyramids are already
+resident in HBM (the reference times exactly Optimize(), pyramids excluded:
+apps/PhotoconsistencyFrameAlignment/PhotoconsistencyFrameAlignment.cpp:99-102).
+
+Workload (BASELINE.json configs[1]): config_files/config_4_level_optimization_analytic.yml on synthetic
+640x480 RGB-D.  The timed region runs it in FIXED-ITERATION mode (min_gradient_norm = 0, so every pair
+executes exactly max_num_iterations = 50 + 20 iterations: deterministic work, the mode SURVEY.md section 8d
+prescribes for the roofline figure).  The shipped thresholds (data-dependent early stop) are measured too and
+reported under "reference_termination" -- that number is higher, it is not `value`.
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); every rank aligns its own contiguous
+shard of the pair list (weak scaling: `--pairs` per GPU) and ONE all_gather per step moves the 6-vector
+results to every rank.  value = pairs of all ranks / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import phovo_amd  # noqa: E402,F401
+from phovo_amd import distributed, native, odometry, synthetic  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+YML = os.path.join(ROOT, "config_files", "config_4_level_optimization_analytic.yml")
+W, H = 640, 480
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=2048, help="frame pairs per GPU per step")
+    ap.add_argument("--distinct", type=int, default=32, help="distinct synthetic pairs generated per GPU")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="bound of the CPU-oracle baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reference-termination", action="store_true")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(level_sizes, iterations):
+    """per GN iteration and pair, 5 fp64 planes of N_L pixels are read once."""
+    return sum(5.0 * 8.0 * n * it for n, it in zip(level_sizes, iterations))
+
+
+def run_steps(eng, src, tgt, steps, world, device, n_global):
+    """Runs `steps` steps; returns (wall seconds of this rank, per-level kernel ms summed over the steps)."""
+    per_level = np.zeros(native.MAX_LEVELS)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.enqueue_align(src, tgt)
+        eng.synchronize()
+        if world > 1:
+            distributed.gather_states(eng.fetch_results(len(src)), n_global, device=device)
+        _, lv = eng.last_align_ms()
+        per_level += np.array(lv)
+    return time.perf_counter() - t0, per_level
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch = dist = device = None
+    if world > 1 or args.gpus > 1:
+        import torch
+        import torch.distributed as dist
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+        dist.init_process_group("nccl", device_id=device)
+
+    if native.lib().phovo_device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: the alignment path has no CPU fallback")
+
+    # ---- synthetic inputs: one sequence per rank, `distinct` pairs, replicated to `pairs` slots ----
+    distinct = max(1, min(args.distinct, args.pairs))
+    seq = synthetic.make_sequence(seed=100 + rank, n_frames=distinct + 1, width=W, height=H, holes=0.01)
+    reps = (args.pairs + distinct - 1) // distinct
+    cfg_ref = native.read_config_file(YML)
+    nl = cfg_ref.num_levels
+    max_iter = list(cfg_ref.max_num_iterations[:nl])
+    cfg_fixed = native.read_config_file(YML)
+    for l in range(nl):
+        cfg_fixed.min_gradient_norm[l] = 0.0
+
+    eng = odometry.AlignmentEngine(local_rank)
+    eng.set_config(cfg_fixed)
+    eng.set_intrinsic_matrix(seq["K"])
+    n_frames = reps * (distinct + 1)
+    eng.reserve_frames(n_frames, W, H)
+    src, tgt = [], []
+    for r in range(reps):                       # every replica has its own copy of the planes in HBM
+        base = r * (distinct + 1)
+        for f in range(distinct + 1):
+            eng.upload_frame(base + f, seq["gray"][f], seq["depth"][f])
+        for t in range(distinct):
+            src.append(base + t)
+            tgt.append(base + t + 1)
+    src, tgt = src[:args.pairs], tgt[:args.pairs]
+    n_local = len(src)
+    n_global = n_local * world
+    level_sizes = [eng.level_size(l)[0] * eng.level_size(l)[1] for l in range(nl)]
+    launch = {l: eng.level_launch_info(l) for l in range(nl) if max_iter[l] > 0}
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        eng.synchronize()
+
+    # ---- timed region: fixed-iteration mode ---------------------------------------------------
+    run_steps(eng, src, tgt, args.warmup, world, device, n_global)
+    barrier()
+    wall, per_level_ms = run_steps(eng, src, tgt, args.steps, world, device, n_global)
+    barrier()
+    if world > 1:
+        tmax = torch.tensor([wall], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        wall = float(tmax.item())
+    states, reports = eng.fetch_results(n_local, want_reports=True)
+    iters = np.array([list(r.iterations[:nl]) for r in reports])
+    nonfinite = int(sum(1 for r in reports if r.flags))
+    value = n_global * args.steps / wall
+    ms_per_step = 1e3 * wall / args.steps
+
+    # per-level roofline: algorithmic bytes of one launch / its average duration (HIP events on the
+    # engine's own stream, one start/stop pair around each level launch)
+    levels_out = []
+    for l in range(nl):
+        if max_iter[l] <= 0:
+            continue
+        it_sum = float(iters[:, l].sum())
+        bytes_launch = 5.0 * 8.0 * level_sizes[l] * it_sum
+        avg_ms = per_level_ms[l] / args.steps
+        levels_out.append(dict(level=l, pixels=level_sizes[l], avg_launch_ms=avg_ms,
+                               iterations_per_pair=it_sum / n_local,
+                               algorithmic_bytes=bytes_launch,
+                               achieved_GBs=bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
+                               **launch[l]))
+    dom = max(levels_out, key=lambda d: d["avg_launch_ms"])
+    total_bytes = sum(d["algorithmic_bytes"] for d in levels_out)
+    total_ms = sum(d["avg_launch_ms"] for d in levels_out)
+    roofline = dict(bound="hbm", kernel=f"gn_level_kernel level {dom['level']} ({dom['pixels']} px)",
+                    achieved=dom["achieved_GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=dom["achieved_GBs"] / HBM_PEAK_GBS, traffic=None,
+                    all_levels_achieved=total_bytes / (total_ms * 1e-3) / 1e9,
+                    all_levels_frac=total_bytes / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    levels=levels_out)
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            t = json.load(open(pmc))
+            if t.get("pairs") == n_local and t.get("level") == dom["level"]:
+                roofline["traffic"] = t["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc, separate run)"
+        except Exception:
+            pass
+
+    # ---- shipped thresholds (reference termination), same resident inputs ---------------------
+    ref_term = None
+    if not args.no_reference_termination:
+        eng.set_config(cfg_ref)
+        run_steps(eng, src, tgt, 1, world, device, n_global)
+        barrier()
+        k2 = max(2, args.steps // 2)
+        wall2, _ = run_steps(eng, src, tgt, k2, world, device, n_global)
+        barrier()
+        if world > 1:
+            tmax = torch.tensor([wall2], dtype=torch.float64, device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            wall2 = float(tmax.item())
+        _, reps2 = eng.fetch_results(n_local, want_reports=True)
+        it2 = np.array([list(r.iterations[:nl]) for r in reps2])
+        ref_term = dict(value=n_global * k2 / wall2, unit="alignments/s", steps=k2,
+                        mean_iterations_per_level=[float(x) for x in it2.mean(axis=0)],
+                        max_iterations_per_level=[int(x) for x in it2.max(axis=0)])
+
+    # ---- CPU baseline: the oracle, one thread, bounded sample of the same workload ------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle
+        ocfg = oracle.make_config(num_levels=nl, max_iter=max_iter, min_grad=[0.0] * nl)
+        done, t_cpu = 0, 0.0
+        for t in range(distinct):
+            i0p, d0p = oracle.build_source_pyramids(seq["gray"][t], seq["depth"][t], ocfg)
+            i1p, gxp, gyp = oracle.build_target_pyramids(seq["gray"][t + 1], ocfg)
+            c0 = time.perf_counter()
+            oracle.optimize(ocfg, seq["K"], i0p, d0p, i1p, gxp, gyp)      # Optimize() only, as the reference times it
+            t_cpu += time.perf_counter() - c0
+            done += 1
+            if t_cpu >= args.cpu_seconds:
+                break
+        cpu = dict(value=done / t_cpu, unit="alignments/s", cores=1, kind="port",
+                   sample=f"{done} of the same synthetic 640x480 pairs, fixed-iteration mode, Optimize() only "
+                          f"({t_cpu:.1f} s, gcc -O3 -mtune=native, single thread as the reference builds)",
+                   host_cpus=os.cpu_count())
+
+    if rank == 0:
+        out = {
+            "metric": "frame-pair alignments/sec (640x480, 4-level)",
+            "value": value,
+            "unit": "alignments/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "config_4_level_optimization_analytic.yml on synthetic 640x480 RGB-D, fixed-iteration "
+                            "mode (min_gradient_norm=0: 50 iterations at 80x60 + 20 at 160x120 per pair), "
+                            "Optimize() only with pyramids resident in HBM",
+                "pairs_per_gpu": n_local, "global_pairs_per_step": n_global,
+                "distinct_pairs_per_gpu": distinct, "image": [W, H], "levels": nl,
+                "max_num_iterations": max_iter, "parallelism": f"pairs sharded x{world}, RCCL all_gather of states",
+            },
+            "iterations_per_pair": [float(x) for x in iters.mean(axis=0)],
+            "nonfinite_pairs": nonfinite,
+            "algorithmic_MB_per_alignment": algorithmic_bytes(
+                level_sizes, [m if max_iter[l] > 0 else 0.0 for l, m in enumerate(iters.mean(axis=0))]) / 1e6,
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "reference_termination": ref_term,
+        }
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

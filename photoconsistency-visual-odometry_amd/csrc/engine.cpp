@@ -300,11 +300,18 @@ int phovo_engine_set_config(phovo_engine *e, const phovo_config *cfg)
   if (!e || !cfg) return fail(PHOVO_E_INVALID_ARGUMENT, "set_config: null");
   const int st = validate_config(cfg);
   if (st != PHOVO_OK) return st;
-  // A new configuration changes which levels exist and how they are built: drop the pool, as the
-  // reference requires the configuration before Set*Frame (:474 uses m_NumOptimizationLevels).
+  // A configuration that changes which levels exist or how their planes are built drops the pool:
+  // the reference requires the configuration before Set*Frame (:474 uses m_NumOptimizationLevels).
+  // Changing only lambda / max_num_iterations (within the resident levels) / min_gradient_norm keeps it.
+  bool keep = e->n_frames > 0 && cfg->num_levels == e->cfg.num_levels;
+  for (int l = 0; keep && l < cfg->num_levels; l++) {
+    if (cfg->blur_filter_size[l] != e->cfg.blur_filter_size[l]) keep = false;
+    if (cfg->image_gradients_scaling_factor[l] != e->cfg.image_gradients_scaling_factor[l]) keep = false;
+    if (cfg->max_num_iterations[l] > 0 && !e->levels[l].stored) keep = false;
+  }
   (void)hipSetDevice(e->device);
   (void)hipStreamSynchronize(e->stream);
-  free_pool(e);
+  if (!keep) free_pool(e);
   e->cfg = *cfg;
   return PHOVO_OK;
 }

@@ -20,7 +20,7 @@
 //           J^T J and J^T r held in registers.
 //   reduce  per-wave transposed butterfly (32 shuffles for 32 values instead of 6 x 27), one LDS row
 //           per wave, fixed-order sum across waves -> bitwise reproducible.
-//   solve   wave 0: 6x6 Gaussian elimination with partial pivoting, state -= lambda * H^-1 g,
+//   solve   wave 0: 6x6 LDL^T solve, state -= lambda * H^-1 g,
 //           termination test, pose constants of the next iteration.
 // No MFMA: J^T J is a 6 x N by N x 6 contraction, a reduction, not a GEMM tile.
 //
@@ -36,7 +36,6 @@ namespace phovo_hip {
 namespace {
 
 constexpr int WAVE = 64;
-constexpr int NACC = 27;     // 21 upper-triangular J^T J + 6 J^T r
 constexpr int NRED = 32;     // padded for the butterfly
 
 // Indices into the pose-constant block in LDS.
@@ -62,13 +61,18 @@ __device__ __forceinline__ double uniform_f64(double v)
 // reference's association.  temp7 = -temp6, temp9 = -temp8, temp21 = -temp5, temp22 = temp2,
 // temp23 = temp1 hold exactly in IEEE arithmetic and are not stored; Rt(0,0) = temp15,
 // Rt(1,0) = temp14, Rt(2,0) = -temp3, Rt(2,1) = temp1, Rt(2,2) = temp2 likewise.
-__device__ void write_pose_constants(const double s[6], double *cst)
+__device__ __forceinline__ void write_pose_constants(double x, double y, double z, double yaw, double pitch,
+                                                     double roll, double *cst, int lane)
 {
-  const double x = s[0], y = s[1], z = s[2];
-  double sy, cy, sp, cp, sr, cr;
-  sincos(s[3], &sy, &cy);
-  sincos(s[4], &sp, &cp);
-  sincos(s[5], &sr, &cr);
+  // Lanes 0, 1, 2 take yaw, pitch, roll: ONE sincos issue instead of three dependent ones; the six
+  // results are then broadcast (the whole wave executes this with a wave-uniform state).
+  const double ang = (lane == 1) ? pitch : ((lane == 2) ? roll : yaw);
+  double sn, cs;
+  sincos(ang, &sn, &cs);
+  const double sy = __shfl(sn, 0, WAVE), cy = __shfl(cs, 0, WAVE);
+  const double sp = __shfl(sn, 1, WAVE), cp = __shfl(cs, 1, WAVE);
+  const double sr = __shfl(sn, 2, WAVE), cr = __shfl(cs, 2, WAVE);
+  if (lane != 0) return;
   cst[C_X] = x; cst[C_Y] = y; cst[C_Z] = z;
   cst[C_R01] = cy * sp * sr - sy * cr;
   cst[C_R02] = cy * sp * cr + sy * sr;
@@ -95,54 +99,90 @@ __device__ void write_pose_constants(const double s[6], double *cst)
   cst[C_T24] = cp;
 }
 
-// One butterfly stage of the transposed wave reduction: N values in, N/2 out.
-template <int N>
+// One butterfly stage of the transposed wave reduction: N values in, N/2 out.  The stage is issued in
+// groups of G exchanges with a scheduling fence between groups: left alone, the scheduler hoists all
+// N/2 select pairs in front of the shuffles and the live range grows by 4 VGPRs per exchange
+// (179 VGPRs and spills under the 128-register budget of a 1024-thread workgroup).
+template <int N, int G>
 __device__ __forceinline__ void reduce_stage(double (&v)[NRED], int lane, int dist)
 {
   const bool up = (lane & dist) != 0;
 #pragma unroll
-  for (int i = 0; i < N / 2; i++) {
-    const double send = up ? v[i] : v[i + N / 2];
-    const double keep = up ? v[i + N / 2] : v[i];
-    v[i] = keep + __shfl_xor(send, dist, WAVE);
+  for (int base = 0; base < N / 2; base += G) {
+#pragma unroll
+    for (int i = base; i < base + G && i < N / 2; i++) {
+      const double send = up ? v[i] : v[i + N / 2];
+      const double keep = up ? v[i + N / 2] : v[i];
+      v[i] = keep + __shfl_xor(send, dist, WAVE);
+    }
+    if (N / 2 > G) __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-// 6x6 solve by Gaussian elimination with partial pivoting, fully unrolled so that every index is a
-// compile-time constant (no scratch).  a is the augmented matrix [H | g]; returns H^-1 g in x.
-__device__ void solve6(double (&a)[6][7], double (&x)[6])
+// 6x6 solve of the normal equations H x = g by an unpivoted LDL^T factorisation: H = J^T J is
+// symmetric positive semi-definite, for which LDL^T is backward stable, needs 6 reciprocals instead of
+// the 21 divisions + 15 row swaps of pivoted elimination and only the 21 upper-triangular sums.
+// (The reference forms H^-1 with Eigen's PartialPivLU, ...Analytic.h:540; both are accurate to
+// cond(H)*eps, far inside the 1e-5 pose bar -- tests/test_gpu_parity.py holds 1e-9.)
+// h is the upper triangle, row-major: h[idx(i,j)], i <= j.  Fully unrolled: every index is a
+// compile-time constant, nothing goes to scratch.
+__device__ __forceinline__ constexpr int tri(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }
+
+__device__ __forceinline__ void solve6_ldlt(const double (&h)[21], const double (&g)[6], double (&x)[6])
 {
+  double L[6][6];       // strictly lower part used
+  double Ld[6][6];      // L[i][k] * d[k]
+  double inv[6];
 #pragma unroll
-  for (int k = 0; k < 6; k++) {
+  for (int j = 0; j < 6; j++) {
+    double dj = h[tri(j, j)];
 #pragma unroll
-    for (int r = k + 1; r < 6; r++) {
-      const bool sw = fabs(a[r][k]) > fabs(a[k][k]);
+    for (int k = 0; k < j; k++) dj = fma(-L[j][k], Ld[j][k], dj);
+    inv[j] = 1.0 / dj;
 #pragma unroll
-      for (int c = k; c < 7; c++) {
-        const double u = a[k][c], l = a[r][c];
-        a[k][c] = sw ? l : u;
-        a[r][c] = sw ? u : l;
-      }
-    }
-    const double piv = a[k][k];
+    for (int i = j + 1; i < 6; i++) {
+      double t = h[tri(j, i)];
 #pragma unroll
-    for (int r = k + 1; r < 6; r++) {
-      const double f = a[r][k] / piv;
-#pragma unroll
-      for (int c = k + 1; c < 7; c++) a[r][c] -= f * a[k][c];
+      for (int k = 0; k < j; k++) t = fma(-L[i][k], Ld[j][k], t);
+      Ld[i][j] = t;
+      L[i][j] = t * inv[j];
     }
   }
+  double y[6];
 #pragma unroll
-  for (int r = 5; r >= 0; r--) {
-    double s = a[r][6];
+  for (int i = 0; i < 6; i++) {
+    double t = g[i];
 #pragma unroll
-    for (int c = r + 1; c < 6; c++) s -= a[r][c] * x[c];
-    x[r] = s / a[r][r];
+    for (int k = 0; k < i; k++) t = fma(-L[i][k], y[k], t);
+    y[i] = t;
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    double t = y[i] * inv[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; k++) t = fma(-L[k][i], x[k], t);
+    x[i] = t;
   }
 }
 
-template <int T, bool SRC_LDS, bool OWNER_LDS>
-__global__ __launch_bounds__(T) void gn_level_kernel(const GNLevelArgs A)
+// 1/x to within one ulp: v_rcp_f64 seeds two Newton steps.  The IEEE-exact division sequence is
+// 11 instructions, this is 5; the half-ulp it gives up is far below the fp64 noise floor of the sums
+// that follow (tests/test_gpu_parity.py holds the poses to 1e-9 against the oracle's exact divisions).
+__device__ __forceinline__ double fast_rcp(double x)
+{
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-x, r, 1.0);
+  return fma(r, e, r);
+}
+
+// T threads per workgroup, WPS = waves per SIMD the register allocator must leave room for
+// (2 workgroups of 512 threads per CU <=> 4).  SRC_LDS: source intensity plane staged in LDS.
+// OWNER_LDS: owner map in LDS (else in global memory).  MASK_REG: the per-pixel "warped in bounds"
+// flags of a lane live in one 64-bit register (needs <= 64 chunks per wave), else in an LDS ballot array.
+template <int T, int WPS, bool SRC_LDS, bool OWNER_LDS, bool MASK_REG>
+__global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
 {
   constexpr int NW = T / WAVE;
   extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -151,8 +191,8 @@ __global__ __launch_bounds__(T) void gn_level_kernel(const GNLevelArgs A)
   double *s_state = s_cst + 32;                                        // [8]
   double *s_red = s_state + 8;                                         // [NW][NRED]
   int *s_ctl = reinterpret_cast<int *>(s_red + NW * NRED);             // [CTL_COUNT]
-  unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(s_ctl + CTL_COUNT);  // [n_chunks]
-  unsigned char *p = reinterpret_cast<unsigned char *>(s_mask + A.n_chunks);
+  unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(s_ctl + CTL_COUNT);  // [n_chunks] (!MASK_REG)
+  unsigned char *p = reinterpret_cast<unsigned char *>(s_mask + (MASK_REG ? 0 : A.n_chunks));
   int *s_owner = reinterpret_cast<int *>(p);                           // [n]      (OWNER_LDS)
   if (OWNER_LDS) p += sizeof(int) * ((A.n + 1) & ~1);
   double *s_i0 = reinterpret_cast<double *>(p);                        // [n]      (SRC_LDS)
@@ -162,7 +202,6 @@ __global__ __launch_bounds__(T) void gn_level_kernel(const GNLevelArgs A)
   const int wave = tid / WAVE;
   const int pair = blockIdx.x;
   const int n = A.n, W = A.w, H = A.h;
-  const float inv_w = 1.0f / (float)W;
 
   const size_t fstride = (size_t)PLANES_PER_FRAME * (size_t)n;
   const double *src_frame = A.planes + (size_t)A.src[pair] * fstride;
@@ -185,10 +224,10 @@ __global__ __launch_bounds__(T) void gn_level_kernel(const GNLevelArgs A)
     double st[6];
 #pragma unroll
     for (int j = 0; j < 6; j++) st[j] = A.states[(size_t)pair * 6 + j];
+    write_pose_constants(st[0], st[1], st[2], st[3], st[4], st[5], s_cst, lane);
     if (lane == 0) {
 #pragma unroll
       for (int j = 0; j < 6; j++) s_state[j] = st[j];
-      write_pose_constants(st, s_cst);
       s_ctl[CTL_DONE] = 0;
       s_ctl[CTL_FLAGS] = 0;
     }
@@ -199,8 +238,21 @@ __global__ __launch_bounds__(T) void gn_level_kernel(const GNLevelArgs A)
   const double min_d = A.min_depth, max_d = A.max_depth;
   const double dW = (double)W, dH = (double)H;
 
+  // A wave walks the image in chunks of 64 consecutive pixels, NW chunks apart; (row, column) of a
+  // lane's pixel is carried along instead of divided out per pixel.
+  const int k0 = wave * WAVE + lane;
+  const int r0 = k0 / W, c0 = k0 - r0 * W;
+  const int step_r = (NW * WAVE) / W, step_c = (NW * WAVE) - step_r * W;
+
   int iteration = 0;
   double last_gnorm = 0.0;
+#ifdef PHOVO_STAMPS
+  unsigned long long st_sum[5] = {0, 0, 0, 0, 0};
+  unsigned long long st_prev = clock64();
+#define PHOVO_STAMP(i) { unsigned long long _n = clock64(); st_sum[i] += _n - st_prev; st_prev = _n; }
+#else
+#define PHOVO_STAMP(i)
+#endif
   while (true) {
     // ---- constants of this iteration (uniform -> SGPRs) -----------------------------------
     const double cx = uniform_f64(s_cst[C_X]), cyy = uniform_f64(s_cst[C_Y]), cz = uniform_f64(s_cst[C_Z]);
@@ -210,37 +262,44 @@ __global__ __launch_bounds__(T) void gn_level_kernel(const GNLevelArgs A)
     const double t14 = uniform_f64(s_cst[C_T14]), t15 = uniform_f64(s_cst[C_T15]);
 
     // ---- pass 1: warp every source pixel, resolve who owns each target pixel -------------
-    for (int chunk = wave; chunk < A.n_chunks; chunk += NW) {
-      const int k = chunk * WAVE + lane;
-      bool inb = false;
-      if (k < n) {
-        const double pz = D0[k];                                        // :279
-        if (min_d < pz && pz < max_d) {                                 // :280
-          int r = (int)(((float)k + 0.5f) * inv_w);
-          int c = k - r * W;
-          if (c < 0) { r -= 1; c += W; }
-          if (c >= W) { r += 1; c -= W; }
-          const double px = ((double)c - ox) * pz * ifx;                // :282
-          const double py = ((double)r - oy) * pz * ify;                // :283
-          const double X = ((t15 * px + r01 * py) + r02 * pz) + cx;     // Rt*point3D  :291
-          const double Y = ((t14 * px + r11 * py) + r12 * pz) + cyy;
-          const double Z = ((-t3 * px + t1 * py) + t2 * pz) + cz;
-          const double iz = 1.0 / Z;                                    // :294
-          const double tc = (X * fx) * iz + ox;                         // :295
-          const double tr = (Y * fy) * iz + oy;                         // :296
-          const double rr = round(tr), rc = round(tc);                  // C round(), half away  :297-298
-          if (rr >= 0.0 && rr < dH && rc >= 0.0 && rc < dW) {           // :302-303 (NaN fails)
-            inb = true;
-            const int t = (int)rr * W + (int)rc;
-            if (OWNER_LDS) atomicMax(&s_owner[t], k);                   // last raster writer wins  :358
-            else atomicMax(&g_owner[t], k);
+    unsigned long long inb_bits = 0ull;
+    {
+      int k = k0, r = r0, c = c0, j = 0;
+      for (int chunk = wave; chunk < A.n_chunks; chunk += NW, j++) {
+        bool inb = false;
+        if (k < n) {
+          const double pz = D0[k];                                        // :279
+          if (min_d < pz && pz < max_d) {                                 // :280
+            const double px = ((double)c - ox) * pz * ifx;                // :282
+            const double py = ((double)r - oy) * pz * ify;                // :283
+            const double X = ((t15 * px + r01 * py) + r02 * pz) + cx;     // Rt*point3D  :291
+            const double Y = ((t14 * px + r11 * py) + r12 * pz) + cyy;
+            const double Z = ((-t3 * px + t1 * py) + t2 * pz) + cz;
+            const double iz = fast_rcp(Z);                                // :294
+            const double tc = (X * fx) * iz + ox;                         // :295
+            const double tr = (Y * fy) * iz + oy;                         // :296
+            const double rr = round(tr), rc = round(tc);                  // C round(), half away  :297-298
+            if (rr >= 0.0 && rr < dH && rc >= 0.0 && rc < dW) {           // :302-303 (NaN fails)
+              inb = true;
+              const int t = (int)rr * W + (int)rc;
+              if (OWNER_LDS) atomicMax(&s_owner[t], k);                   // last raster writer wins  :358
+              else atomicMax(&g_owner[t], k);
+            }
           }
         }
+        if (MASK_REG) {
+          inb_bits |= (unsigned long long)(inb ? 1u : 0u) << j;
+        } else {
+          const unsigned long long m = __ballot(inb);
+          if (lane == 0) s_mask[chunk] = m;
+        }
+        k += NW * WAVE; c += step_c; r += step_r;
+        if (c >= W) { c -= W; r += 1; }
       }
-      const unsigned long long m = __ballot(inb);
-      if (lane == 0) s_mask[chunk] = m;
     }
+    PHOVO_STAMP(0)
     __syncthreads();
+    PHOVO_STAMP(1)
 
     // ---- pass 2: residual, Jacobian row, normal-equation accumulation ---------------------
     const double t4 = uniform_f64(s_cst[C_T4]), t5 = uniform_f64(s_cst[C_T5]), t6 = uniform_f64(s_cst[C_T6]);
@@ -254,83 +313,81 @@ __global__ __launch_bounds__(T) void gn_level_kernel(const GNLevelArgs A)
 #pragma unroll
     for (int j = 0; j < NRED; j++) acc[j] = 0.0;
 
-    for (int chunk = wave; chunk < A.n_chunks; chunk += NW) {
-      const int k = chunk * WAVE + lane;
-      int o = -1;
-      if (k < n) {
-        if (OWNER_LDS) {
-          o = s_owner[k];
-          s_owner[k] = -1;                        // ready for the next iteration
-        } else {
-          o = __hip_atomic_load(&g_owner[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(&g_owner[k], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-      const unsigned long long m = s_mask[chunk];
-      if (m == 0ull) continue;                    // wave-uniform
-      if ((m >> lane) & 1ull) {
-        const double pz = D0[k];
-        const double gxi = GX[k];                 // gradient at the SOURCE index  :346-347
-        const double gyi = GY[k];
-        double res = 0.0;
-        if (o >= 0) {
-          const double pixel1 = SRC_LDS ? s_i0[o] : I0[o];              // :308 of the owning source pixel
-          const double pixel2 = I1[k];                                  // :309
-          res = pixel2 - pixel1;                                        // :358
-        }
-        int r = (int)(((float)k + 0.5f) * inv_w);
-        int c = k - r * W;
-        if (c < 0) { r -= 1; c += W; }
-        if (c >= W) { r += 1; c -= W; }
-        const double px = ((double)c - ox) * pz * ifx;
-        const double py = ((double)r - oy) * pz * ify;
-
-        const double t25 = 1.0 / (cz + py * t1 + pz * t2 - px * t3);    // :313
-        const double t26 = t25 * t25;                                   // :314
-        const double Au = pz * t4 + py * t5 + px * t11;                 // (pz*temp4+py*temp5+px*temp11)
-        const double Bv = py * t6 + pz * t9 + px * t14 + cyy;           // (py*temp6+pz*temp9+px*temp14+y)
-        const double Cm = -py * t16 - pz * t17 - px * t24;              // d(Z)/d(pitch)
-        const double Dm = py * t2 - pz * t1;                            // (py*temp22-pz*temp23)
-
-        const double ju0 = fx * t25;                                                    // :317
-        const double jv1 = fy * t25;                                                    // :322
-        const double ju2 = -fx * Au * t26;                                              // :325
-        const double jv2 = -fy * Bv * t26;                                              // :326
-        const double ju3 = fx * (py * t7 + pz * t8 - px * t14) * t25;                   // :329
-        const double jv3 = fy * (pz * t4 + py * t5 + px * t15) * t25;                   // :330
-        const double ju4 = fx * (py * t10 + pz * t12 - px * t13) * t25 - fx * Cm * Au * t26;   // :333-334
-        const double jv4 = fy * (py * t18 + pz * t19 - px * t20) * t25 - fy * Cm * Bv * t26;   // :335-336
-        const double ju5 = fx * (py * t4 + pz * t21) * t25 - fx * Dm * Au * t26;        // :339-340
-        const double jv5 = fy * (pz * t7 + py * t9) * t25 - fy * Dm * Bv * t26;         // :341-342
-
-        double J[6];                                                                    // :348
-        J[0] = gxi * ju0 + gyi * 0.0;
-        J[1] = gxi * 0.0 + gyi * jv1;
-        J[2] = gxi * ju2 + gyi * jv2;
-        J[3] = gxi * ju3 + gyi * jv3;
-        J[4] = gxi * ju4 + gyi * jv4;
-        J[5] = gxi * ju5 + gyi * jv5;
-
-        int q = 0;
-#pragma unroll
-        for (int a = 0; a < 6; a++) {
-#pragma unroll
-          for (int b = a; b < 6; b++) {
-            acc[q] = fma(J[a], J[b], acc[q]);                                           // J^T J  :540
-            q++;
+    {
+      int k = k0, r = r0, c = c0, j = 0;
+      for (int chunk = wave; chunk < A.n_chunks; chunk += NW, j++) {
+        int o = -1;
+        if (k < n) {
+          if (OWNER_LDS) {
+            o = s_owner[k];
+            s_owner[k] = -1;                        // ready for the next iteration
+          } else {
+            o = __hip_atomic_load(&g_owner[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&g_owner[k], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
+        const bool mine = MASK_REG ? (((inb_bits >> j) & 1ull) != 0ull)
+                                   : (((s_mask[chunk] >> lane) & 1ull) != 0ull);
+        if (mine) {
+          const double pz = D0[k];
+          const double gxi = GX[k];                 // gradient at the SOURCE index  :346-347
+          const double gyi = GY[k];
+          double res = 0.0;
+          if (o >= 0) {
+            const double pixel1 = SRC_LDS ? s_i0[o] : I0[o];              // :308 of the owning source pixel
+            const double pixel2 = I1[k];                                  // :309
+            res = pixel2 - pixel1;                                        // :358
+          }
+          const double px = ((double)c - ox) * pz * ifx;
+          const double py = ((double)r - oy) * pz * ify;
+
+          // The 2x6 warp Jacobian (:312-342) contracted with the image gradient (:348), with the common
+          // factors pulled out:  temp25 = 1/Z, temp26 = temp25^2,
+          //   Au = (pz*temp4+py*temp5+px*temp11)   [temp11 carries the reference's bug, :253]
+          //   Bv = (py*temp6+pz*temp9+px*temp14+y)
+          //   Cm = (-py*temp16-pz*temp17-px*temp24), Dm = (py*temp22-pz*temp23)
+          //   J0 = gx*fx*temp25, J1 = gy*fy*temp25, J2 = -(gx*fx*Au + gy*fy*Bv)*temp26,
+          //   J3 = J0*(py*temp7+pz*temp8-px*temp14) + J1*(pz*temp4+py*temp5+px*temp15),
+          //   J4 = J0*(py*temp10+pz*temp12-px*temp13) + J1*(py*temp18+pz*temp19-px*temp20) + Cm*J2,
+          //   J5 = J0*(py*temp4+pz*temp21) + J1*(pz*temp7+py*temp9) + Dm*J2.
+          const double t25 = fast_rcp(cz + py * t1 + pz * t2 - px * t3);  // :313
+          const double Au = pz * t4 + py * t5 + px * t11;
+          const double Bv = py * t6 + pz * t9 + px * t14 + cyy;
+          const double Cm = -py * t16 - pz * t17 - px * t24;
+          const double Dm = py * t2 - pz * t1;
+          double J[6];
+          J[0] = (gxi * fx) * t25;                                        // :317
+          J[1] = (gyi * fy) * t25;                                        // :322
+          J[2] = -(J[0] * Au + J[1] * Bv) * t25;                          // :325-326
+          J[3] = J[0] * (py * t7 + pz * t8 - px * t14) + J[1] * (pz * t4 + py * t5 + px * t15);        // :329-330
+          J[4] = J[0] * (py * t10 + pz * t12 - px * t13) + J[1] * (py * t18 + pz * t19 - px * t20)
+                 + Cm * J[2];                                                                            // :333-336
+          J[5] = J[0] * (py * t4 + pz * t21) + J[1] * (pz * t7 + py * t9) + Dm * J[2];                   // :339-342
+
+          int q = 0;
 #pragma unroll
-        for (int a = 0; a < 6; a++) acc[21 + a] = fma(J[a], res, acc[21 + a]);           // J^T r  :538
+          for (int a = 0; a < 6; a++) {
+#pragma unroll
+            for (int b = a; b < 6; b++) {
+              acc[q] = fma(J[a], J[b], acc[q]);                                         // J^T J  :540
+              q++;
+            }
+          }
+#pragma unroll
+          for (int a = 0; a < 6; a++) acc[21 + a] = fma(J[a], res, acc[21 + a]);         // J^T r  :538
+        }
+        k += NW * WAVE; c += step_c; r += step_r;
+        if (c >= W) { c -= W; r += 1; }
       }
     }
 
+    PHOVO_STAMP(2)
     // ---- wave-level transposed butterfly: 32 shuffles, lane l ends with value index idx(l) ----
-    reduce_stage<32>(acc, lane, 32);
-    reduce_stage<16>(acc, lane, 16);
-    reduce_stage<8>(acc, lane, 8);
-    reduce_stage<4>(acc, lane, 4);
-    reduce_stage<2>(acc, lane, 2);
+    reduce_stage<32, 4>(acc, lane, 32);
+    reduce_stage<16, 4>(acc, lane, 16);
+    reduce_stage<8, 4>(acc, lane, 8);
+    reduce_stage<4, 4>(acc, lane, 4);
+    reduce_stage<2, 4>(acc, lane, 2);
     {
       const double total = acc[0] + __shfl_xor(acc[0], 1, WAVE);
       const int idx = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 +
@@ -338,34 +395,27 @@ __global__ __launch_bounds__(T) void gn_level_kernel(const GNLevelArgs A)
       if ((lane & 1) == 0) s_red[wave * NRED + idx] = total;
     }
     __syncthreads();
+    PHOVO_STAMP(3)
 
     // ---- wave 0: cross-wave sum (fixed order), solve, update, terminate ------------------------
     if (wave == 0) {
+      // lane l sums value (l & 31) over half of the waves, the halves meet in one shuffle
       double v = 0.0;
-      if (lane < NRED) {
-#pragma unroll 4
-        for (int w2 = 0; w2 < NW; w2++) v += s_red[w2 * NRED + lane];
-      }
-      double a[6][7];
       {
-        int q = 0;
+        const int j = lane & (NRED - 1);
+        const int w0 = (lane >> 5) * (NW / 2);
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-#pragma unroll
-          for (int j = i; j < 6; j++) {
-            const double hij = __shfl(v, q, WAVE);
-            a[i][j] = hij;
-            a[j][i] = hij;
-            q++;
-          }
-        }
+        for (int w2 = 0; w2 < NW / 2; w2++) v += s_red[(w0 + w2) * NRED + j];
+        v += __shfl_xor(v, 32, WAVE);
       }
-      double g[6];
+      double h[21], g[6];
 #pragma unroll
-      for (int i = 0; i < 6; i++) { g[i] = __shfl(v, 21 + i, WAVE); a[i][6] = g[i]; }
+      for (int q = 0; q < 21; q++) h[q] = __shfl(v, q, WAVE);
+#pragma unroll
+      for (int i = 0; i < 6; i++) g[i] = __shfl(v, 21 + i, WAVE);
 
       double step[6];
-      solve6(a, step);
+      solve6_ldlt(h, g, step);
       double st[6];
       bool finite = true;
 #pragma unroll
@@ -382,16 +432,17 @@ __global__ __launch_bounds__(T) void gn_level_kernel(const GNLevelArgs A)
       if (it >= A.max_iter) done = true;                                                // :383
       else if (gnorm < A.min_grad_norm) done = true;                                    // :388
       if (!finite) done = true;     // the reference would keep iterating on NaN; the result is the same NaN
+      if (!done) write_pose_constants(st[0], st[1], st[2], st[3], st[4], st[5], s_cst, lane);   // wave-uniform branch
       if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < 6; i++) s_state[i] = st[i];
         s_ctl[CTL_DONE] = done ? 1 : 0;
         if (!finite) s_ctl[CTL_FLAGS] |= (int)PHOVO_PAIR_NONFINITE;
-        if (!done) write_pose_constants(st, s_cst);
       }
       last_gnorm = gnorm;
     }
     __syncthreads();
+    PHOVO_STAMP(4)
     iteration++;
     if (s_ctl[CTL_DONE]) break;
   }
@@ -404,63 +455,85 @@ __global__ __launch_bounds__(T) void gn_level_kernel(const GNLevelArgs A)
       A.reports[pair].iterations[A.level] = iteration;
       A.reports[pair].gradient_norm = last_gnorm;
       A.reports[pair].flags |= (uint32_t)s_ctl[CTL_FLAGS];
+#ifdef PHOVO_STAMPS
+      // diagnostic build only: phase cycle sums of wave 0 go to the otherwise unused report slots 8..12
+      for (int j = 0; j < 5; j++) A.reports[pair].iterations[8 + j] = (int)(st_sum[j] / (unsigned long long)iteration);
+#endif
     }
   }
 }
 
-size_t lds_fixed_bytes(int threads, int n_chunks)
+constexpr size_t LDS_LIMIT = 160 * 1024;   // MI355X: 160 KiB per CU, one workgroup may take all of it
+constexpr size_t LDS_HALF = LDS_LIMIT / 2; // two workgroups per CU
+
+size_t lds_fixed_bytes(int threads)
 {
   const int nw = threads / WAVE;
-  return sizeof(double) * (32 + 8 + (size_t)nw * NRED) + sizeof(int) * CTL_COUNT +
-         sizeof(unsigned long long) * (size_t)n_chunks;
+  return sizeof(double) * (32 + 8 + (size_t)nw * NRED) + sizeof(int) * CTL_COUNT;
 }
 
-constexpr size_t LDS_LIMIT = 160 * 1024;   // MI355X: 160 KiB per CU, one workgroup may take all of it
+// The instantiations that exist (each one is a separate kernel in the code object):
+//   SMALL  512 threads, 2 workgroups/CU, owner map + source intensity in LDS, register mask
+//   MID    512 threads, 2 workgroups/CU, owner map in LDS, register mask
+//   WIDE   1024 threads, 1 workgroup/CU, owner map in LDS (80..160 KB), register mask
+//   HUGE   1024 threads, owner map in global memory, ballot mask in LDS
+//   TINY   256 threads, 4 workgroups/CU, everything in LDS (levels of <= 2048 pixels)
+enum Variant { V_TINY = 0, V_SMALL, V_MID, V_WIDE, V_HUGE };
 
-template <int T, bool SRC_LDS, bool OWNER_LDS>
-hipError_t launch_inst(const GNLevelArgs &a, int n_pairs, size_t lds, hipStream_t stream)
-{
-  hipLaunchKernelGGL((gn_level_kernel<T, SRC_LDS, OWNER_LDS>), dim3(n_pairs), dim3(T), lds, stream, a);
-  return hipGetLastError();
-}
-
-template <int T, bool SRC_LDS, bool OWNER_LDS>
-hipError_t prepare_inst()
-{
-  return hipFuncSetAttribute(reinterpret_cast<const void *>(&gn_level_kernel<T, SRC_LDS, OWNER_LDS>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
-}
+#define PHOVO_KERNEL_TINY  gn_level_kernel<256, 4, true, true, true>
+#define PHOVO_KERNEL_SMALL gn_level_kernel<512, 4, true, true, true>
+#define PHOVO_KERNEL_MID   gn_level_kernel<512, 4, false, true, true>
+#define PHOVO_KERNEL_WIDE  gn_level_kernel<1024, 4, false, true, true>
+#define PHOVO_KERNEL_HUGE  gn_level_kernel<1024, 4, false, false, false>
 
 }  // namespace
 
 bool gn_plan_level(int n, GNLaunchPlan *plan)
 {
-  const int n_chunks = (n + WAVE - 1) / WAVE;
-  // Workgroup size: enough waves to cover the level a few times over, at most 1024 threads.
-  int threads = 1024;
-  if (n <= 64 * 4) threads = 256;
-  else if (n <= 64 * 16) threads = 512;
-  const size_t fixed = lds_fixed_bytes(threads, n_chunks);
-  if (fixed > LDS_LIMIT) return false;
+  const size_t n_chunks = (size_t)(n + WAVE - 1) / WAVE;
   const size_t owner = sizeof(int) * (size_t)((n + 1) & ~1);
   const size_t src = sizeof(double) * (size_t)n;
-  plan->threads = threads;
-  plan->owner_in_lds = fixed + owner <= LDS_LIMIT;
-  plan->source_in_lds = plan->owner_in_lds && (fixed + owner + src <= LDS_LIMIT);
-  plan->lds_bytes = (int)(fixed + (plan->owner_in_lds ? owner : 0) + (plan->source_in_lds ? src : 0));
+  if (n <= 2048) {
+    plan->variant = V_TINY; plan->threads = 256; plan->owner_in_lds = true; plan->source_in_lds = true;
+    plan->lds_bytes = (int)(lds_fixed_bytes(256) + owner + src);
+    return true;
+  }
+  const size_t f512 = lds_fixed_bytes(512), f1024 = lds_fixed_bytes(1024);
+  const bool reg512 = n_chunks <= 64 * 8, reg1024 = n_chunks <= 64 * 16;
+  if (reg512 && f512 + owner + src <= LDS_HALF) {
+    plan->variant = V_SMALL; plan->threads = 512; plan->owner_in_lds = true; plan->source_in_lds = true;
+    plan->lds_bytes = (int)(f512 + owner + src);
+    return true;
+  }
+  if (reg512 && f512 + owner <= LDS_HALF) {
+    plan->variant = V_MID; plan->threads = 512; plan->owner_in_lds = true; plan->source_in_lds = false;
+    plan->lds_bytes = (int)(f512 + owner);
+    return true;
+  }
+  if (reg1024 && f1024 + owner <= LDS_LIMIT) {
+    plan->variant = V_WIDE; plan->threads = 1024; plan->owner_in_lds = true; plan->source_in_lds = false;
+    plan->lds_bytes = (int)(f1024 + owner);
+    return true;
+  }
+  const size_t mask = sizeof(unsigned long long) * n_chunks;
+  if (f1024 + mask > LDS_LIMIT) return false;
+  plan->variant = V_HUGE; plan->threads = 1024; plan->owner_in_lds = false; plan->source_in_lds = false;
+  plan->lds_bytes = (int)(f1024 + mask);
   return true;
 }
 
 hipError_t gn_prepare_kernels()
 {
   hipError_t e;
-#define PHOVO_PREP(T)                                                     \
-  if ((e = prepare_inst<T, true, true>()) != hipSuccess) return e;        \
-  if ((e = prepare_inst<T, false, true>()) != hipSuccess) return e;       \
-  if ((e = prepare_inst<T, false, false>()) != hipSuccess) return e;
-  PHOVO_PREP(256)
-  PHOVO_PREP(512)
-  PHOVO_PREP(1024)
+#define PHOVO_PREP(K)                                                                             \
+  e = hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                          (int)LDS_LIMIT);                                                        \
+  if (e != hipSuccess) return e;
+  PHOVO_PREP(PHOVO_KERNEL_TINY)
+  PHOVO_PREP(PHOVO_KERNEL_SMALL)
+  PHOVO_PREP(PHOVO_KERNEL_MID)
+  PHOVO_PREP(PHOVO_KERNEL_WIDE)
+  PHOVO_PREP(PHOVO_KERNEL_HUGE)
 #undef PHOVO_PREP
   return hipSuccess;
 }
@@ -470,17 +543,16 @@ hipError_t gn_launch_level(const GNLevelArgs &a, const GNLaunchPlan &plan, int n
 {
   if (n_pairs <= 0) return hipSuccess;
   const size_t lds = (size_t)plan.lds_bytes;
-#define PHOVO_DISPATCH(T)                                                                   \
-  if (plan.threads == T) {                                                                  \
-    if (plan.source_in_lds) return launch_inst<T, true, true>(a, n_pairs, lds, stream);     \
-    if (plan.owner_in_lds) return launch_inst<T, false, true>(a, n_pairs, lds, stream);     \
-    return launch_inst<T, false, false>(a, n_pairs, lds, stream);                           \
+  const dim3 grid((unsigned)n_pairs), block((unsigned)plan.threads);
+  switch (plan.variant) {
+    case V_TINY:  hipLaunchKernelGGL(PHOVO_KERNEL_TINY, grid, block, lds, stream, a); break;
+    case V_SMALL: hipLaunchKernelGGL(PHOVO_KERNEL_SMALL, grid, block, lds, stream, a); break;
+    case V_MID:   hipLaunchKernelGGL(PHOVO_KERNEL_MID, grid, block, lds, stream, a); break;
+    case V_WIDE:  hipLaunchKernelGGL(PHOVO_KERNEL_WIDE, grid, block, lds, stream, a); break;
+    case V_HUGE:  hipLaunchKernelGGL(PHOVO_KERNEL_HUGE, grid, block, lds, stream, a); break;
+    default: return hipErrorInvalidValue;
   }
-  PHOVO_DISPATCH(256)
-  PHOVO_DISPATCH(512)
-  PHOVO_DISPATCH(1024)
-#undef PHOVO_DISPATCH
-  return hipErrorInvalidValue;
+  return hipGetLastError();
 }
 
 }  // namespace phovo_hip

@@ -33,6 +33,7 @@ struct GNLevelArgs {
 };
 
 struct GNLaunchPlan {
+  int variant;              // which instantiation of the level kernel (gn_kernels.hip)
   int threads;              // workgroup size
   int lds_bytes;            // dynamic LDS
   bool owner_in_lds;

@@ -8,7 +8,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libphovo_hip.so")
+# PHOVO_HIP_LIBRARY selects a diagnostic build (e.g. the phase-stamp build of csrc/Makefile `stamps`).
+_SO = os.environ.get("PHOVO_HIP_LIBRARY") or os.path.join(_HERE, "libphovo_hip.so")
 _CSRC = os.path.join(_HERE, "csrc")
 MAX_LEVELS = 16
 
