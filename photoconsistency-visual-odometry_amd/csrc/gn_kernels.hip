@@ -29,6 +29,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "phovo_internal.hpp"
 
 namespace phovo_hip {
@@ -116,6 +118,27 @@ __device__ __forceinline__ void reduce_stage(double (&v)[NRED], int lane, int di
       v[i] = keep + __shfl_xor(send, dist, WAVE);
     }
     if (N / 2 > G) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// The two widest butterfly stages without selects or LDS-crossbar traffic: gfx950's
+// v_permlane32_swap / v_permlane16_swap exchange the upper half (odd 16-lane rows) of one register with
+// the lower half (even rows) of another, so for the pair (v[i], v[i+N/2]) one swap per dword leaves
+//   newA = { own v[i] in the low lanes,  partner's v[i+N/2] in the high lanes }
+//   newB = { partner's v[i] in the low lanes,  own v[i+N/2] in the high lanes }
+// and newA + newB is exactly "keep + received" of reduce_stage with the same lane -> index map.
+template <int N, bool ROW16>
+__device__ __forceinline__ void reduce_stage_swap(double (&v)[NRED])
+{
+#pragma unroll
+  for (int i = 0; i < N / 2; i++) {
+    const unsigned alo = (unsigned)__double2loint(v[i]), ahi = (unsigned)__double2hiint(v[i]);
+    const unsigned blo = (unsigned)__double2loint(v[i + N / 2]), bhi = (unsigned)__double2hiint(v[i + N / 2]);
+    const auto lo = ROW16 ? __builtin_amdgcn_permlane16_swap(alo, blo, false, false)
+                          : __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+    const auto hi = ROW16 ? __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false)
+                          : __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    v[i] = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
   }
 }
 
@@ -268,7 +291,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
       for (int chunk = wave; chunk < A.n_chunks; chunk += NW, j++) {
         bool inb = false;
         if (k < n) {
-          const double pz = D0[k];                                        // :279
+          const double pz = D0[(unsigned)k];                              // :279
           if (min_d < pz && pz < max_d) {                                 // :280
             const double px = ((double)c - ox) * pz * ifx;                // :282
             const double py = ((double)r - oy) * pz * ify;                // :283
@@ -281,7 +304,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
             const double rr = round(tr), rc = round(tc);                  // C round(), half away  :297-298
             if (rr >= 0.0 && rr < dH && rc >= 0.0 && rc < dW) {           // :302-303 (NaN fails)
               inb = true;
-              const int t = (int)rr * W + (int)rc;
+              const int t = __mul24((int)rr, W) + (int)rc;           // both < 2^24: full-rate 24-bit multiply
               if (OWNER_LDS) atomicMax(&s_owner[t], k);                   // last raster writer wins  :358
               else atomicMax(&g_owner[t], k);
             }
@@ -329,13 +352,13 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
         const bool mine = MASK_REG ? (((inb_bits >> j) & 1ull) != 0ull)
                                    : (((s_mask[chunk] >> lane) & 1ull) != 0ull);
         if (mine) {
-          const double pz = D0[k];
-          const double gxi = GX[k];                 // gradient at the SOURCE index  :346-347
-          const double gyi = GY[k];
+          const double pz = D0[(unsigned)k];
+          const double gxi = GX[(unsigned)k];       // gradient at the SOURCE index  :346-347
+          const double gyi = GY[(unsigned)k];
           double res = 0.0;
           if (o >= 0) {
-            const double pixel1 = SRC_LDS ? s_i0[o] : I0[o];              // :308 of the owning source pixel
-            const double pixel2 = I1[k];                                  // :309
+            const double pixel1 = SRC_LDS ? s_i0[o] : I0[(unsigned)o];    // :308 of the owning source pixel
+            const double pixel2 = I1[(unsigned)k];                                  // :309
             res = pixel2 - pixel1;                                        // :358
           }
           const double px = ((double)c - ox) * pz * ifx;
@@ -383,8 +406,8 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
 
     PHOVO_STAMP(2)
     // ---- wave-level transposed butterfly: 32 shuffles, lane l ends with value index idx(l) ----
-    reduce_stage<32, 4>(acc, lane, 32);
-    reduce_stage<16, 4>(acc, lane, 16);
+    reduce_stage_swap<32, false>(acc);
+    reduce_stage_swap<16, true>(acc);
     reduce_stage<8, 4>(acc, lane, 8);
     reduce_stage<4, 4>(acc, lane, 4);
     reduce_stage<2, 4>(acc, lane, 2);
@@ -478,13 +501,15 @@ size_t lds_fixed_bytes(int threads)
 //   WIDE   1024 threads, 1 workgroup/CU, owner map in LDS (80..160 KB), register mask
 //   HUGE   1024 threads, owner map in global memory, ballot mask in LDS
 //   TINY   256 threads, 4 workgroups/CU, everything in LDS (levels of <= 2048 pixels)
-enum Variant { V_TINY = 0, V_SMALL, V_MID, V_WIDE, V_HUGE };
+//   QUAD   256 threads, 4 workgroups/CU, owner map in LDS, source intensity gathered from L2
+enum Variant { V_TINY = 0, V_SMALL, V_MID, V_WIDE, V_HUGE, V_QUAD };
 
 #define PHOVO_KERNEL_TINY  gn_level_kernel<256, 4, true, true, true>
 #define PHOVO_KERNEL_SMALL gn_level_kernel<512, 4, true, true, true>
 #define PHOVO_KERNEL_MID   gn_level_kernel<512, 4, false, true, true>
 #define PHOVO_KERNEL_WIDE  gn_level_kernel<1024, 4, false, true, true>
 #define PHOVO_KERNEL_HUGE  gn_level_kernel<1024, 4, false, false, false>
+#define PHOVO_KERNEL_QUAD  gn_level_kernel<256, 4, false, true, true>
 
 }  // namespace
 
@@ -496,6 +521,16 @@ bool gn_plan_level(int n, GNLaunchPlan *plan)
   if (n <= 2048) {
     plan->variant = V_TINY; plan->threads = 256; plan->owner_in_lds = true; plan->source_in_lds = true;
     plan->lds_bytes = (int)(lds_fixed_bytes(256) + owner + src);
+    return true;
+  }
+  const size_t f256 = lds_fixed_bytes(256);
+  // Four 256-thread workgroups per CU beat two of 512 on levels this small (80x60: 4.31 vs 4.64 ms per
+  // 2048 pairs x 50 iterations): while one workgroup's wave 0 solves, three others keep the SIMDs busy.
+  // PHOVO_GN_NO_QUAD=1 is a tuning aid for tools/ only.
+  static const bool no_quad = std::getenv("PHOVO_GN_NO_QUAD") != nullptr;
+  if (!no_quad && n_chunks <= 64 * 4 && f256 + owner <= LDS_LIMIT / 4) {
+    plan->variant = V_QUAD; plan->threads = 256; plan->owner_in_lds = true; plan->source_in_lds = false;
+    plan->lds_bytes = (int)(f256 + owner);
     return true;
   }
   const size_t f512 = lds_fixed_bytes(512), f1024 = lds_fixed_bytes(1024);
@@ -534,6 +569,7 @@ hipError_t gn_prepare_kernels()
   PHOVO_PREP(PHOVO_KERNEL_MID)
   PHOVO_PREP(PHOVO_KERNEL_WIDE)
   PHOVO_PREP(PHOVO_KERNEL_HUGE)
+  PHOVO_PREP(PHOVO_KERNEL_QUAD)
 #undef PHOVO_PREP
   return hipSuccess;
 }
@@ -550,6 +586,7 @@ hipError_t gn_launch_level(const GNLevelArgs &a, const GNLaunchPlan &plan, int n
     case V_MID:   hipLaunchKernelGGL(PHOVO_KERNEL_MID, grid, block, lds, stream, a); break;
     case V_WIDE:  hipLaunchKernelGGL(PHOVO_KERNEL_WIDE, grid, block, lds, stream, a); break;
     case V_HUGE:  hipLaunchKernelGGL(PHOVO_KERNEL_HUGE, grid, block, lds, stream, a); break;
+    case V_QUAD:  hipLaunchKernelGGL(PHOVO_KERNEL_QUAD, grid, block, lds, stream, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
