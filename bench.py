@@ -78,9 +78,18 @@ def main():
         import torch.distributed as dist
         if world != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
-        torch.cuda.set_device(local_rank)
-        device = torch.device("cuda", local_rank)
-        dist.init_process_group("nccl", device_id=device)
+        # PHOVO_BENCH_BACKEND=gloo is a rehearsal aid for a one-GPU box (RCCL refuses two ranks on one
+        # device); the driver's multi-GPU runs use the default, nccl (= RCCL on ROCm).
+        backend = os.environ.get("PHOVO_BENCH_BACKEND", "nccl")
+        n_dev = native.lib().phovo_device_count()
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            device = torch.device("cuda", local_rank)
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            local_rank = local_rank % max(n_dev, 1)
+            device = torch.device("cpu")
+            dist.init_process_group(backend)
 
     if native.lib().phovo_device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: the alignment path has no CPU fallback")
@@ -118,7 +127,8 @@ def main():
     def barrier():
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            if device.type == "cuda":
+                torch.cuda.synchronize()
         eng.synchronize()
 
     # ---- timed region: fixed-iteration mode ---------------------------------------------------
@@ -193,18 +203,17 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle
         ocfg = oracle.make_config(num_levels=nl, max_iter=max_iter, min_grad=[0.0] * nl)
-        done, t_cpu = 0, 0.0
-        for t in range(distinct):
+        done, t_cpu, t = 0, 0.0, 0
+        while t_cpu < args.cpu_seconds:
             i0p, d0p = oracle.build_source_pyramids(seq["gray"][t], seq["depth"][t], ocfg)
             i1p, gxp, gyp = oracle.build_target_pyramids(seq["gray"][t + 1], ocfg)
             c0 = time.perf_counter()
             oracle.optimize(ocfg, seq["K"], i0p, d0p, i1p, gxp, gyp)      # Optimize() only, as the reference times it
             t_cpu += time.perf_counter() - c0
             done += 1
-            if t_cpu >= args.cpu_seconds:
-                break
+            t = (t + 1) % distinct
         cpu = dict(value=done / t_cpu, unit="alignments/s", cores=1, kind="port",
-                   sample=f"{done} of the same synthetic 640x480 pairs, fixed-iteration mode, Optimize() only "
+                   sample=f"{done} alignments over the same synthetic 640x480 pairs, fixed-iteration mode, Optimize() only "
                           f"({t_cpu:.1f} s, gcc -O3 -mtune=native, single thread as the reference builds)",
                    host_cpus=os.cpu_count())
 

@@ -188,6 +188,20 @@ __device__ __forceinline__ void solve6_ldlt(const double (&h)[21], const double 
   }
 }
 
+// Plane loads go through buffer descriptors: the four planes of a chunk share ONE 32-bit byte offset
+// (8*k) in a VGPR while the bases sit in SGPRs, and a read past the plane returns 0 instead of needing
+// a branch (raw buffer, num_records = plane bytes).  Flat loads cost a 64-bit VGPR address per plane.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const double *p, int n)
+{
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p), 0, n * 8, 0x00020000);
+}
+__device__ __forceinline__ double plane_load(__amdgpu_buffer_rsrc_t r, int byte_off)
+{
+  const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0);
+  return __hiloint2double((int)v.y, (int)v.x);
+}
+
 // 1/x to within one ulp: v_rcp_f64 seeds two Newton steps.  The IEEE-exact division sequence is
 // 11 instructions, this is 5; the half-ulp it gives up is far below the fp64 noise floor of the sums
 // that follow (tests/test_gpu_parity.py holds the poses to 1e-9 against the oracle's exact divisions).
@@ -235,6 +249,8 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
   const double *__restrict__ GX = tgt_frame + (size_t)PLANE_GX * n;
   const double *__restrict__ GY = tgt_frame + (size_t)PLANE_GY * n;
   int *g_owner = OWNER_LDS ? nullptr : A.g_owner + (size_t)pair * (size_t)n;
+  const __amdgpu_buffer_rsrc_t rI0 = plane_rsrc(I0, n), rD0 = plane_rsrc(D0, n);
+  const __amdgpu_buffer_rsrc_t rI1 = plane_rsrc(I1, n), rGX = plane_rsrc(GX, n), rGY = plane_rsrc(GY, n);
 
   // ---- level prologue -------------------------------------------------------------------
   if (OWNER_LDS) {
@@ -288,11 +304,15 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
     unsigned long long inb_bits = 0ull;
     {
       int k = k0, r = r0, c = c0, j = 0;
+      // software prefetch: the depth of the NEXT chunk is requested before this chunk is processed, so
+      // every wave keeps a load in flight while it computes (the passes are bound by bytes in flight per CU)
+      double pz_next = plane_load(rD0, k * 8);
       for (int chunk = wave; chunk < A.n_chunks; chunk += NW, j++) {
+        const double pz = pz_next;                                        // :279
+        pz_next = plane_load(rD0, (k + NW * WAVE) * 8);                   // past the plane: 0
         bool inb = false;
-        if (k < n) {
-          const double pz = D0[(unsigned)k];                              // :279
-          if (min_d < pz && pz < max_d) {                                 // :280
+        {
+          if (k < n && min_d < pz && pz < max_d) {                        // :280
             const double px = ((double)c - ox) * pz * ifx;                // :282
             const double py = ((double)r - oy) * pz * ify;                // :283
             const double X = ((t15 * px + r01 * py) + r02 * pz) + cx;     // Rt*point3D  :291
@@ -338,29 +358,37 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
 
     {
       int k = k0, r = r0, c = c0, j = 0;
-      for (int chunk = wave; chunk < A.n_chunks; chunk += NW, j++) {
-        int o = -1;
-        if (k < n) {
+      // software prefetch, as in pass 1: owner + four planes of the NEXT chunk are requested (and the
+      // gathered source intensity right behind them) before this chunk's arithmetic starts.
+      int o_n = -1;
+      double pz_n = 0.0, gx_n = 0.0, gy_n = 0.0, i1_n = 0.0, i0_n = 0.0;
+      auto fetch = [&](int kk) {
+        o_n = -1;
+        if (kk < n) {
           if (OWNER_LDS) {
-            o = s_owner[k];
-            s_owner[k] = -1;                        // ready for the next iteration
+            o_n = s_owner[kk];
+            s_owner[kk] = -1;                       // ready for the next iteration
           } else {
-            o = __hip_atomic_load(&g_owner[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&g_owner[k], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            o_n = __hip_atomic_load(&g_owner[kk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&g_owner[kk], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
+        pz_n = plane_load(rD0, kk * 8);
+        gx_n = plane_load(rGX, kk * 8);             // gradient at the SOURCE index  :346-347
+        gy_n = plane_load(rGY, kk * 8);
+        i1_n = plane_load(rI1, kk * 8);             // :309
+        if (SRC_LDS) { if (o_n >= 0) i0_n = s_i0[o_n]; }
+        else i0_n = plane_load(rI0, o_n * 8);       // :308 of the owning source pixel (o = -1: offset past the plane -> 0)
+      };
+      fetch(k);
+      for (int chunk = wave; chunk < A.n_chunks; chunk += NW, j++) {
+        const int o = o_n;
+        const double pz = pz_n, gxi = gx_n, gyi = gy_n, pixel2 = i1_n, pixel1 = i0_n;
+        fetch(k + NW * WAVE);
         const bool mine = MASK_REG ? (((inb_bits >> j) & 1ull) != 0ull)
                                    : (((s_mask[chunk] >> lane) & 1ull) != 0ull);
         if (mine) {
-          const double pz = D0[(unsigned)k];
-          const double gxi = GX[(unsigned)k];       // gradient at the SOURCE index  :346-347
-          const double gyi = GY[(unsigned)k];
-          double res = 0.0;
-          if (o >= 0) {
-            const double pixel1 = SRC_LDS ? s_i0[o] : I0[(unsigned)o];    // :308 of the owning source pixel
-            const double pixel2 = I1[(unsigned)k];                                  // :309
-            res = pixel2 - pixel1;                                        // :358
-          }
+          const double res = (o >= 0) ? (pixel2 - pixel1) : 0.0;          // :358
           const double px = ((double)c - ox) * pz * ifx;
           const double py = ((double)r - oy) * pz * ify;
 

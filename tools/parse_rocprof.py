@@ -1,0 +1,70 @@
+"""Turns the rocprofv3 outputs of one profiling session into the files kept under profiles/:
+
+    python tools/parse_rocprof.py gpurun_out/prof_r01 profiles r01
+
+Inputs (directories written by the commands in profiles/README.md):
+  stats/      --kernel-trace --stats                     -> <tag>_kernel_stats.csv (copied)
+  pmc_fetch/  --pmc FETCH_SIZE   of the same bench command
+  pmc_write/  --pmc WRITE_SIZE   of the same bench command
+  cal_fetch/, cal_write/   the same counters on tools/pmc_calibrate.py (a copy kernel of known size)
+Output: <tag>_pmc_traffic.json (+ pmc_traffic.json for bench.py) with HBM bytes per launch of each
+Gauss-Newton level kernel, corrected as MI355X_MICROARCH.md (HBM section) prescribes: the counters are
+calibrated on a known byte count in the kernel's own access pattern (8 B per lane, coalesced) and the
+measured factor is applied."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+
+def counter_rows(d):
+    f = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
+    if not f:
+        return []
+    return list(csv.DictReader(open(f[0])))
+
+
+def mean_by_kernel(rows, skip_first=0):
+    acc = defaultdict(list)
+    for r in rows:
+        acc[(r["Kernel_Name"], int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
+    return {k: sum(v[skip_first:]) / max(1, len(v[skip_first:])) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
+
+
+def main():
+    src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+    os.makedirs(dst, exist_ok=True)
+    for f in glob.glob(os.path.join(src, "stats", "**", "*_kernel_stats.csv"), recursive=True):
+        shutil.copy(f, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+
+    # calibration: k_resize_level<double> at level 0 = 640x480 doubles read and written once
+    known = 640 * 480 * 8
+    cal = {}
+    for name, d in (("FETCH_SIZE", "cal_fetch"), ("WRITE_SIZE", "cal_write")):
+        m, _ = mean_by_kernel(counter_rows(os.path.join(src, d)))
+        vals = [v for (k, g), v in m.items() if "k_resize_level<double>" in k and g == 768 * 480]
+        cal[name] = dict(counter_KB=vals[0] if vals else None, known_bytes=known,
+                         factor=(known / (vals[0] * 1024.0)) if vals and vals[0] > 0 else None)
+
+    out = dict(tag=tag, calibration=cal, kernels=[])
+    fetch, nf = mean_by_kernel(counter_rows(os.path.join(src, "pmc_fetch")), skip_first=2)
+    write, _ = mean_by_kernel(counter_rows(os.path.join(src, "pmc_write")), skip_first=2)
+    for (k, g), v in sorted(fetch.items()):
+        if "gn_level_kernel" not in k:
+            continue
+        w = write.get((k, g), 0.0)
+        ff = cal["FETCH_SIZE"]["factor"] or 1.0
+        wf = cal["WRITE_SIZE"]["factor"] or 1.0
+        out["kernels"].append(dict(kernel=k, grid_size=g, dispatches=nf[(k, g)],
+                                   FETCH_SIZE_KB=v, WRITE_SIZE_KB=w,
+                                   hbm_read_bytes=v * 1024.0 * ff, hbm_write_bytes=w * 1024.0 * wf,
+                                   hbm_bytes_per_launch=v * 1024.0 * ff + w * 1024.0 * wf))
+    json.dump(out, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
