@@ -1,0 +1,208 @@
+// PhotoconsistencyVisualOdometry on the MI355X path: frame-to-frame odometry over a TUM-format RGB-D
+// directory, writing a TUM trajectory file.
+//
+//   ./PhotoconsistencyVisualOdometry <config_file.yml> <rgbd_dataset_directory> <output_trajectory_file> [--batch]
+//
+// Behaviour kept from the reference's app (apps/PhotoconsistencyVisualOdometry/PhotoconsistencyVisualOdometry.cpp):
+//   * <dir>/rgb.txt and <dir>/depth.txt are read in lock step -- line n of one is paired with line n of the
+//     other, there is NO timestamp association (phovo/include/CMultiSensorDataSource.h:74-91); '#' lines are
+//     skipped and image paths are relative to the list file (CCameraRecord.h:74-108);
+//   * intrinsics (517.3, 516.5, 318.6, 255.3) and depth scale 1/5000 are hard-coded (:163,170-173);
+//   * every pair starts from the zero state (:175,224) -> pairs are independent;
+//   * pose *= Rt^-1, quaternion from the rotation block, one line `timestamp tx ty tz qx qy qz qw` with 16
+//     significant digits per pair, stamped with the CURRENT rgb timestamp (:233-243).
+// Default mode goes pair by pair through the class surface exactly like the reference's loop and prints
+// `Time = ... sec.` and `Rt:` for each.  --batch loads the whole sequence, builds every pyramid once on the
+// GPU (the reference builds each frame's pyramids twice, :222-223) and aligns all pairs in one batched call;
+// the trajectory is identical.
+#include <sys/stat.h>
+
+#include <chrono>
+#include <cstdlib>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <limits>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "io/png_io.h"
+#include "phovo/CPhotoconsistencyOdometryAnalytic.h"
+
+typedef double CoordinateType;
+typedef unsigned char PixelType;
+typedef phovo::Numeric::Matrix33RowMajor<CoordinateType> Matrix33Type;
+typedef phovo::Numeric::Matrix44RowMajor<CoordinateType> Matrix44Type;
+typedef phovo::Numeric::VectorCol6<CoordinateType> Vector6Type;
+typedef phovo::Numeric::Quaternion<CoordinateType> QuaternionType;
+typedef phovo::compat::Mat_<PixelType> IntensityImageType;
+typedef phovo::compat::Mat_<CoordinateType> DepthImageType;
+
+struct ListEntry { double timestamp; std::string path; };
+
+static bool fileExists(const std::string &p) { struct stat st; return ::stat(p.c_str(), &st) == 0; }
+
+static std::string parentDir(const std::string &p)
+{
+  const size_t s = p.find_last_of('/');
+  return s == std::string::npos ? std::string(".") : p.substr(0, s);
+}
+
+static bool readList(const std::string &listFile, std::vector<ListEntry> &out)
+{
+  std::ifstream in(listFile.c_str());
+  if (!in.is_open()) { std::cerr << "Unable to open camera record file " << listFile << std::endl; return false; }
+  const std::string dir = parentDir(listFile);
+  std::string line;
+  while (std::getline(in, line)) {
+    if (line.empty() || line[0] == '#') continue;
+    std::istringstream iss(line);
+    ListEntry e;
+    std::string name;
+    if (!(iss >> e.timestamp >> name)) continue;
+    e.path = dir + "/" + name;
+    out.push_back(e);
+  }
+  return true;
+}
+
+static bool loadGray(const std::string &path, IntensityImageType &img)
+{
+  phovo_io::Image8 im; std::string err;
+  if (!phovo_io::read_gray8(path, &im, &err)) { std::cerr << err << std::endl; return false; }
+  img.create(im.height, im.width);
+  for (size_t i = 0; i < im.pixels.size(); i++) img.data[i] = im.pixels[i];
+  return true;
+}
+
+static bool loadDepth16(const std::string &path, phovo_io::Image16 &im)
+{
+  std::string err;
+  if (!phovo_io::read_unchanged16(path, &im, &err)) { std::cerr << err << std::endl; return false; }
+  return true;
+}
+
+static void writePose(std::ofstream &f, double timestamp, const Matrix44Type &pose)
+{
+  const Matrix33Type R = pose.block<3, 3>(0, 0);
+  const QuaternionType q(R);
+  f << std::setprecision(std::numeric_limits<double>::digits10 + 1) << timestamp << " "
+    << pose(0, 3) << " " << pose(1, 3) << " " << pose(2, 3) << " "
+    << q.x() << " " << q.y() << " " << q.z() << " " << q.w() << std::endl;
+}
+
+static void printHelp()
+{
+  std::cout << "./PhotoconsistencyVisualOdometry <config_file.yml> <rgbd_dataset_directory> "
+               "<output_trajectory_file> [--batch]" << std::endl;
+}
+
+#define PHOVO_OK_OR_FAIL(call)                                                              \
+  do { if ((call) != PHOVO_OK) { std::cerr << #call << ": " << phovo_last_error() << std::endl; return EXIT_FAILURE; } } while (0)
+
+int main(int argc, char *argv[])
+{
+  if (argc < 4) { printHelp(); return EXIT_FAILURE; }
+  const std::string configFile(argv[1]), datasetDir(argv[2]), trajectoryPath(argv[3]);
+  const bool batch = argc > 4 && std::string(argv[4]) == "--batch";
+  if (!fileExists(configFile)) { std::cerr << "Input config file " << configFile << " does not exist" << std::endl; return EXIT_FAILURE; }
+  if (!fileExists(datasetDir)) { std::cerr << "Input RGBD dataset directory " << datasetDir << " does not exist" << std::endl; return EXIT_FAILURE; }
+  const std::string rgbList = datasetDir + "/rgb.txt", depthList = datasetDir + "/depth.txt";
+  if (!fileExists(rgbList)) { std::cerr << "Input RGB data file " << rgbList << " does not exist" << std::endl; return EXIT_FAILURE; }
+  if (!fileExists(depthList)) { std::cerr << "Input depth data file " << depthList << " does not exist" << std::endl; return EXIT_FAILURE; }
+  const std::string outDir = parentDir(trajectoryPath);
+  if (!fileExists(outDir) && ::mkdir(outDir.c_str(), 0777) != 0) {
+    std::cerr << "Cannot create output directory " << outDir << std::endl;
+    return EXIT_FAILURE;
+  }
+
+  const CoordinateType depthScalingFactor = 1. / 5000.;                    // :163
+  Matrix33Type intrinsicMatrix;                                              // :170-173
+  intrinsicMatrix << 517.3, 0., 318.6,
+                     0., 516.5, 255.3,
+                     0., 0., 1.;
+
+  std::vector<ListEntry> rgb, depth;
+  if (!readList(rgbList, rgb) || !readList(depthList, depth)) return EXIT_FAILURE;
+  const size_t nFrames = rgb.size() < depth.size() ? rgb.size() : depth.size();   // lock step: stops at the shorter list
+
+  std::ofstream trajectoryFile(trajectoryPath.c_str());
+  if (!trajectoryFile.is_open()) { std::cerr << "Cannot open output trajectory file " << trajectoryPath << std::endl; return EXIT_FAILURE; }
+  trajectoryFile << "# estimated trajectory" << std::endl;                    // :187-188
+  trajectoryFile << "# timestamp tx ty tz qx qy qz qw" << std::endl;
+  if (nFrames < 2) return EXIT_SUCCESS;
+
+  Matrix44Type pose = Matrix44Type::Identity();
+  try {
+    if (!batch) {
+      phovo::Analytic::CPhotoconsistencyOdometryAnalytic<PixelType, CoordinateType> odometry;
+      odometry.ReadConfigurationFile(configFile);
+      odometry.SetIntrinsicMatrix(intrinsicMatrix);
+      IntensityImageType prevGray, curGray;
+      DepthImageType prevDepth, curDepth;
+      phovo_io::Image16 d16;
+      if (!loadGray(rgb[0].path, prevGray) || !loadDepth16(depth[0].path, d16)) return EXIT_FAILURE;
+      prevDepth.create(d16.height, d16.width);
+      for (size_t i = 0; i < d16.pixels.size(); i++) prevDepth.data[i] = (double)d16.pixels[i] * depthScalingFactor;
+      for (size_t t = 1; t < nFrames; t++) {
+        if (!loadGray(rgb[t].path, curGray) || !loadDepth16(depth[t].path, d16)) return EXIT_FAILURE;
+        curDepth.create(d16.height, d16.width);
+        for (size_t i = 0; i < d16.pixels.size(); i++) curDepth.data[i] = (double)d16.pixels[i] * depthScalingFactor;
+
+        odometry.SetSourceFrame(prevGray, prevDepth);                        // :222-224
+        odometry.SetTargetFrame(curGray, curDepth);
+        odometry.SetInitialStateVector(Vector6Type::Zero());
+        const auto t0 = std::chrono::steady_clock::now();
+        odometry.Optimize();
+        const auto t1 = std::chrono::steady_clock::now();
+        std::cout << "Time = " << std::chrono::duration<double>(t1 - t0).count() << " sec." << std::endl;
+
+        const Matrix44Type Rt = odometry.GetOptimalRigidTransformationMatrix();
+        pose *= Rt.inverse();                                                // :233-234
+        writePose(trajectoryFile, rgb[t].timestamp, pose);
+        std::cout << "Rt:" << std::endl << Rt << std::endl;
+        prevGray = curGray.clone();
+        prevDepth = curDepth.clone();
+      }
+    } else {
+      phovo_config cfg;
+      PHOVO_OK_OR_FAIL(phovo_config_read_file(configFile.c_str(), &cfg));
+      phovo_engine *engine = nullptr;
+      PHOVO_OK_OR_FAIL(phovo_engine_create(0, &engine));
+      PHOVO_OK_OR_FAIL(phovo_engine_set_config(engine, &cfg));
+      PHOVO_OK_OR_FAIL(phovo_engine_set_intrinsic_matrix(engine, intrinsicMatrix.data()));
+      IntensityImageType gray;
+      phovo_io::Image16 d16;
+      for (size_t t = 0; t < nFrames; t++) {
+        if (!loadGray(rgb[t].path, gray) || !loadDepth16(depth[t].path, d16)) return EXIT_FAILURE;
+        if (t == 0) PHOVO_OK_OR_FAIL(phovo_engine_reserve_frames(engine, (int)nFrames, gray.cols, gray.rows));
+        PHOVO_OK_OR_FAIL(phovo_engine_upload_frame_u16(engine, (int)t, PHOVO_ROLE_BOTH, gray.data, gray.step,
+                                                       d16.pixels.data(), sizeof(uint16_t) * (size_t)d16.width,
+                                                       depthScalingFactor));
+      }
+      const int nPairs = (int)nFrames - 1;
+      std::vector<int> src(nPairs), tgt(nPairs);
+      for (int p = 0; p < nPairs; p++) { src[p] = p; tgt[p] = p + 1; }
+      std::vector<double> states((size_t)nPairs * 6);
+      const auto t0 = std::chrono::steady_clock::now();
+      PHOVO_OK_OR_FAIL(phovo_engine_align_pairs(engine, nPairs, src.data(), tgt.data(), nullptr, states.data(), nullptr));
+      const auto t1 = std::chrono::steady_clock::now();
+      std::cout << "Time = " << std::chrono::duration<double>(t1 - t0).count() << " sec. (" << nPairs << " pairs)" << std::endl;
+      for (int p = 0; p < nPairs; p++) {
+        double rt[16];
+        phovo_eigen_pose(&states[(size_t)p * 6], rt);
+        Matrix44Type Rt;
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) Rt(i, j) = rt[4 * i + j];
+        pose *= Rt.inverse();
+        writePose(trajectoryFile, rgb[(size_t)p + 1].timestamp, pose);
+      }
+      phovo_engine_destroy(engine);
+    }
+  } catch (const std::exception &e) {
+    std::cerr << "error: " << e.what() << std::endl;
+    return EXIT_FAILURE;
+  }
+  trajectoryFile.close();
+  return EXIT_SUCCESS;
+}
