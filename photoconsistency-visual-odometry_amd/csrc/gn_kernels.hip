@@ -568,7 +568,8 @@ bool gn_plan_level(int n, GNLaunchPlan *plan)
     plan->lds_bytes = (int)(f512 + owner + src);
     return true;
   }
-  if (reg512 && f512 + owner <= LDS_HALF) {
+  static const bool force_wide = std::getenv("PHOVO_GN_FORCE_WIDE") != nullptr;     // tuning aid
+  if (!force_wide && reg512 && f512 + owner <= LDS_HALF) {
     plan->variant = V_MID; plan->threads = 512; plan->owner_in_lds = true; plan->source_in_lds = false;
     plan->lds_bytes = (int)(f512 + owner);
     return true;
