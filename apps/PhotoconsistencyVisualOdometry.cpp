@@ -17,6 +17,7 @@
 // the trajectory is identical.
 #include <sys/stat.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <fstream>
@@ -172,15 +173,27 @@ int main(int argc, char *argv[])
       PHOVO_OK_OR_FAIL(phovo_engine_create(0, &engine));
       PHOVO_OK_OR_FAIL(phovo_engine_set_config(engine, &cfg));
       PHOVO_OK_OR_FAIL(phovo_engine_set_intrinsic_matrix(engine, intrinsicMatrix.data()));
+      // Frames are decoded into two packed host arrays and handed over in one batched call: one copy and one
+      // producer launch per pyramid level for every 32 frames.
       IntensityImageType gray;
       phovo_io::Image16 d16;
+      std::vector<uint8_t> allGray;
+      std::vector<uint16_t> allDepth;
+      int W = 0, H = 0;
       for (size_t t = 0; t < nFrames; t++) {
         if (!loadGray(rgb[t].path, gray) || !loadDepth16(depth[t].path, d16)) return EXIT_FAILURE;
-        if (t == 0) PHOVO_OK_OR_FAIL(phovo_engine_reserve_frames(engine, (int)nFrames, gray.cols, gray.rows));
-        PHOVO_OK_OR_FAIL(phovo_engine_upload_frame_u16(engine, (int)t, PHOVO_ROLE_BOTH, gray.data, gray.step,
-                                                       d16.pixels.data(), sizeof(uint16_t) * (size_t)d16.width,
-                                                       depthScalingFactor));
+        if (t == 0) { W = gray.cols; H = gray.rows; allGray.resize((size_t)W * H * nFrames); allDepth.resize((size_t)W * H * nFrames); }
+        if (gray.cols != W || gray.rows != H || d16.width != W || d16.height != H) {
+          std::cerr << "frame " << t << " has a different size" << std::endl;
+          return EXIT_FAILURE;
+        }
+        std::copy(gray.data, gray.data + (size_t)W * H, allGray.begin() + (size_t)W * H * t);
+        std::copy(d16.pixels.begin(), d16.pixels.end(), allDepth.begin() + (size_t)W * H * t);
       }
+      PHOVO_OK_OR_FAIL(phovo_engine_reserve_frames(engine, (int)nFrames, W, H));
+      PHOVO_OK_OR_FAIL(phovo_engine_upload_frames_u16(engine, 0, (int)nFrames, PHOVO_ROLE_BOTH, allGray.data(), (size_t)W,
+                                                      (size_t)W * H, allDepth.data(), sizeof(uint16_t) * (size_t)W,
+                                                      sizeof(uint16_t) * (size_t)W * H, depthScalingFactor));
       const int nPairs = (int)nFrames - 1;
       std::vector<int> src(nPairs), tgt(nPairs);
       for (int p = 0; p < nPairs; p++) { src[p] = p; tgt[p] = p + 1; }

@@ -113,8 +113,7 @@ def main():
     src, tgt = [], []
     for r in range(reps):                       # every replica has its own copy of the planes in HBM
         base = r * (distinct + 1)
-        for f in range(distinct + 1):
-            eng.upload_frame(base + f, seq["gray"][f], seq["depth"][f])
+        eng.upload_frames(base, seq["gray"], seq["depth"])
         for t in range(distinct):
             src.append(base + t)
             tgt.append(base + t + 1)

@@ -148,6 +148,16 @@ int phovo_engine_upload_frame(phovo_engine *e, int frame, int roles,
 int phovo_engine_upload_frame_u16(phovo_engine *e, int frame, int roles,
                                   const uint8_t *intensity, size_t intensity_stride,
                                   const uint16_t *depth, size_t depth_stride, double depth_scale);
+/* Batched forms: `count` consecutive pool slots starting at first_frame, frames `*_frame_stride` BYTES
+ * apart in host memory (rows `*_stride` bytes apart).  One host->device copy and one producer launch per
+ * pyramid level for up to 32 frames at a time, instead of a copy, six launches and a sync per frame. */
+int phovo_engine_upload_frames(phovo_engine *e, int first_frame, int count, int roles,
+                               const uint8_t *intensity, size_t intensity_stride, size_t intensity_frame_stride,
+                               const double *depth, size_t depth_stride, size_t depth_frame_stride);
+int phovo_engine_upload_frames_u16(phovo_engine *e, int first_frame, int count, int roles,
+                                   const uint8_t *intensity, size_t intensity_stride, size_t intensity_frame_stride,
+                                   const uint16_t *depth, size_t depth_stride, size_t depth_frame_stride,
+                                   double depth_scale);
 /* Direct access to the fp64 planes of one level of one frame (w*h doubles each, NULL = skip):
  * lets a caller supply pyramids built elsewhere (e.g. by OpenCV) or read back the device-built ones. */
 int phovo_engine_set_level_planes(phovo_engine *e, int frame, int level,

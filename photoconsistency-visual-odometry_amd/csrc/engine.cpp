@@ -56,6 +56,9 @@ struct phovo_engine {
 
   int n_frames = 0, width = 0, height = 0;
   LevelPool levels[PHOVO_MAX_LEVELS];
+  // staging for raw frames: `stage_frames` frames of each kind that has been used so far
+  int stage_frames = 0;
+  bool stage_has_f64 = false, stage_has_u16 = false;
   uint8_t *d_gray = nullptr;
   double *d_depth = nullptr;
   uint16_t *d_depth16 = nullptr;
@@ -87,6 +90,7 @@ void free_pool(phovo_engine *e)
   if (e->d_blur_kernel) (void)hipFree(e->d_blur_kernel);
   e->d_gray = nullptr; e->d_depth = nullptr; e->d_depth16 = nullptr; e->d_tmp = nullptr;
   e->d_blur_kernel = nullptr;
+  e->stage_frames = 0; e->stage_has_f64 = e->stage_has_u16 = false;
   e->n_frames = 0; e->width = 0; e->height = 0;
 }
 
@@ -138,27 +142,66 @@ int ensure_pairs(phovo_engine *e, int n_pairs)
   return PHOVO_OK;
 }
 
-int build_frame_pyramids(phovo_engine *e, int frame, int roles)
+enum DepthKind { DEPTH_NONE = 0, DEPTH_F64 = 1, DEPTH_U16 = 2 };
+constexpr int STAGE_CHUNK = 32;      // frames copied and processed per batch of producer launches
+
+// Makes sure the staging buffers hold `frames` raw frames of the kinds asked for.
+int ensure_stage(phovo_engine *e, int frames, bool want_f64, bool want_u16)
+{
+  const size_t px = (size_t)e->width * (size_t)e->height;
+  const bool grow = frames > e->stage_frames;
+  if (grow || (want_f64 && !e->stage_has_f64) || (want_u16 && !e->stage_has_u16)) {
+    PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
+    const int cap = grow ? frames : e->stage_frames;
+    want_f64 = want_f64 || e->stage_has_f64;
+    want_u16 = want_u16 || e->stage_has_u16;
+    if (e->d_gray) (void)hipFree(e->d_gray);
+    if (e->d_depth) (void)hipFree(e->d_depth);
+    if (e->d_depth16) (void)hipFree(e->d_depth16);
+    e->d_gray = nullptr; e->d_depth = nullptr; e->d_depth16 = nullptr;
+    e->stage_frames = 0; e->stage_has_f64 = e->stage_has_u16 = false;
+    PHOVO_HIP_CHECK(hipMalloc(&e->d_gray, px * (size_t)cap));
+    if (want_f64) PHOVO_HIP_CHECK(hipMalloc(&e->d_depth, px * (size_t)cap * sizeof(double)));
+    if (want_u16) PHOVO_HIP_CHECK(hipMalloc(&e->d_depth16, px * (size_t)cap * sizeof(uint16_t)));
+    e->stage_frames = cap; e->stage_has_f64 = want_f64; e->stage_has_u16 = want_u16;
+  }
+  return PHOVO_OK;
+}
+
+// Builds the pyramids of `count` consecutive frames whose raw data sits in the staging buffers:
+// one launch per (level, producer) for the whole batch.
+int build_pyramids(phovo_engine *e, int first_frame, int count, int roles, DepthKind kind, double depth_scale)
 {
   const int w = e->width, h = e->height;
+  const size_t px = (size_t)w * (size_t)h;
   for (int l = 0; l < e->cfg.num_levels; l++) {
     LevelPool &lv = e->levels[l];
     if (!lv.stored) continue;
-    double *base = lv.planes + (size_t)frame * PLANES_PER_FRAME * (size_t)lv.n;
-    double *pi = base + (size_t)PLANE_I * lv.n, *pd = base + (size_t)PLANE_D * lv.n;
-    double *pgx = base + (size_t)PLANE_GX * lv.n, *pgy = base + (size_t)PLANE_GY * lv.n;
+    const size_t fstride = (size_t)PLANES_PER_FRAME * (size_t)lv.n;
+    double *base = lv.planes + (size_t)first_frame * fstride;
     // BuildPyramid(intensity, applyBlur = true)  :474,487
-    PHOVO_HIP_CHECK(pyr_intensity_level(e->d_gray, w, h, l, lv.w, lv.h, pi, e->stream));
+    PHOVO_HIP_CHECK(pyr_intensity_level(e->d_gray, px, count, w, h, l, lv.w, lv.h,
+                                        base + (size_t)PLANE_I * lv.n, fstride, e->stream));
     const int ks = e->cfg.blur_filter_size[l];
     if (ks > 0) {                                                       // GaussianBlur twice  :144-148
       const double *kern = e->d_blur_kernel + (size_t)l * e->blur_kernel_stride;
-      PHOVO_HIP_CHECK(pyr_gaussian_blur(pi, e->d_tmp, lv.w, lv.h, ks, kern, e->stream));
-      PHOVO_HIP_CHECK(pyr_gaussian_blur(pi, e->d_tmp, lv.w, lv.h, ks, kern, e->stream));
+      for (int f = 0; f < count; f++) {
+        double *pi = base + (size_t)f * fstride + (size_t)PLANE_I * lv.n;
+        PHOVO_HIP_CHECK(pyr_gaussian_blur(pi, e->d_tmp, lv.w, lv.h, ks, kern, e->stream));
+        PHOVO_HIP_CHECK(pyr_gaussian_blur(pi, e->d_tmp, lv.w, lv.h, ks, kern, e->stream));
+      }
     }
-    if (roles & PHOVO_ROLE_SOURCE)                                      // BuildPyramid(depth, false)  :475
-      PHOVO_HIP_CHECK(pyr_depth_level(e->d_depth, w, h, l, lv.w, lv.h, pd, e->stream));
+    if (roles & PHOVO_ROLE_SOURCE) {                                    // BuildPyramid(depth, false)  :475
+      double *pd = base + (size_t)PLANE_D * lv.n;
+      if (kind == DEPTH_U16)
+        PHOVO_HIP_CHECK(pyr_depth_level_u16(e->d_depth16, px, depth_scale, count, w, h, l, lv.w, lv.h, pd, fstride, e->stream));
+      else
+        PHOVO_HIP_CHECK(pyr_depth_level(e->d_depth, px, count, w, h, l, lv.w, lv.h, pd, fstride, e->stream));
+    }
     if (roles & PHOVO_ROLE_TARGET)                                      // BuildDerivativesPyramids  :490
-      PHOVO_HIP_CHECK(pyr_scharr(pi, lv.w, lv.h, e->cfg.image_gradients_scaling_factor[l], pgx, pgy, e->stream));
+      PHOVO_HIP_CHECK(pyr_scharr(base, fstride, (size_t)PLANE_I * lv.n, (size_t)PLANE_GX * lv.n,
+                                 (size_t)PLANE_GY * lv.n, count, lv.w, lv.h,
+                                 e->cfg.image_gradients_scaling_factor[l], e->stream));
   }
   return PHOVO_OK;
 }
@@ -377,10 +420,7 @@ int phovo_engine_reserve_frames(phovo_engine *e, int n_frames, int width, int he
     }
     if (e->cfg.blur_filter_size[l] > max_ks) max_ks = e->cfg.blur_filter_size[l];
   }
-  const size_t px = (size_t)width * (size_t)height;
-  hipError_t he = hipMalloc(&e->d_gray, px);
-  if (he == hipSuccess) he = hipMalloc(&e->d_depth, px * sizeof(double));
-  if (he == hipSuccess) he = hipMalloc(&e->d_depth16, px * sizeof(uint16_t));
+  hipError_t he = hipSuccess;        // raw-frame staging is allocated on first upload (ensure_stage)
   if (he == hipSuccess && max_ks > 0) {
     he = hipMalloc(&e->d_tmp, sizeof(double) * (max_n ? max_n : 1));
     if (he == hipSuccess) he = hipMalloc(&e->d_blur_kernel, sizeof(double) * (size_t)max_ks * PHOVO_MAX_LEVELS);
@@ -427,49 +467,89 @@ int phovo_engine_level_is_stored(const phovo_engine *e, int level)
   return e->levels[level].stored ? 1 : 0;
 }
 
-static int upload_common(phovo_engine *e, int frame, int roles, const uint8_t *intensity, size_t istride)
+// Copies `count` frames (rows `stride` bytes apart, frames `frame_stride` bytes apart) into a packed
+// staging buffer.
+static int stage_frames_h2d(phovo_engine *e, void *dst, const void *src, size_t stride, size_t frame_stride,
+                            size_t elem, int count)
 {
-  if (!e || !intensity) return fail(PHOVO_E_INVALID_ARGUMENT, "upload_frame: null");
-  if (e->n_frames == 0) return fail(PHOVO_E_NOT_READY, "upload_frame: reserve_frames first");
-  if (frame < 0 || frame >= e->n_frames) return fail(PHOVO_E_INVALID_ARGUMENT, "upload_frame: frame index out of range");
-  if ((roles & PHOVO_ROLE_BOTH) == 0) return fail(PHOVO_E_INVALID_ARGUMENT, "upload_frame: roles empty");
+  const size_t row = elem * (size_t)e->width, frame_bytes = row * (size_t)e->height;
+  if (stride == row && (frame_stride == frame_bytes || count == 1)) {
+    PHOVO_HIP_CHECK(hipMemcpyAsync(dst, src, frame_bytes * (size_t)count, hipMemcpyHostToDevice, e->stream));
+    return PHOVO_OK;
+  }
+  for (int f = 0; f < count; f++) {
+    const int st = copy_rows_to_device(static_cast<char *>(dst) + frame_bytes * (size_t)f,
+                                       static_cast<const char *>(src) + frame_stride * (size_t)f, stride, row,
+                                       e->height, e->stream);
+    if (st != PHOVO_OK) return st;
+  }
+  return PHOVO_OK;
+}
+
+static int upload_batch(phovo_engine *e, int first_frame, int count, int roles,
+                        const uint8_t *intensity, size_t istride, size_t iframe_stride,
+                        const void *depth, size_t dstride, size_t dframe_stride, DepthKind kind, double scale)
+{
+  if (!e || !intensity) return fail(PHOVO_E_INVALID_ARGUMENT, "upload_frames: null");
+  if (e->n_frames == 0) return fail(PHOVO_E_NOT_READY, "upload_frames: reserve_frames first");
+  if (count < 0 || first_frame < 0 || first_frame + count > e->n_frames)
+    return fail(PHOVO_E_INVALID_ARGUMENT, "upload_frames: frame range out of the reserved pool");
+  if ((roles & PHOVO_ROLE_BOTH) == 0) return fail(PHOVO_E_INVALID_ARGUMENT, "upload_frames: roles empty");
+  if ((roles & PHOVO_ROLE_SOURCE) && !depth) return fail(PHOVO_E_INVALID_ARGUMENT, "upload_frames: a source frame needs depth");
+  if (!(roles & PHOVO_ROLE_SOURCE)) kind = DEPTH_NONE;
+  if (count == 0) return PHOVO_OK;
   PHOVO_HIP_CHECK(hipSetDevice(e->device));
-  return copy_rows_to_device(e->d_gray, intensity, istride, (size_t)e->width, e->height, e->stream);
+  const int chunk_cap = count < STAGE_CHUNK ? count : STAGE_CHUNK;
+  int st = ensure_stage(e, chunk_cap, kind == DEPTH_F64, kind == DEPTH_U16);
+  if (st != PHOVO_OK) return st;
+  for (int done = 0; done < count; done += chunk_cap) {
+    const int c = count - done < chunk_cap ? count - done : chunk_cap;
+    st = stage_frames_h2d(e, e->d_gray, intensity + iframe_stride * (size_t)done, istride, iframe_stride, 1, c);
+    if (st != PHOVO_OK) return st;
+    if (kind == DEPTH_F64)
+      st = stage_frames_h2d(e, e->d_depth, static_cast<const char *>(depth) + dframe_stride * (size_t)done, dstride,
+                            dframe_stride, sizeof(double), c);
+    else if (kind == DEPTH_U16)
+      st = stage_frames_h2d(e, e->d_depth16, static_cast<const char *>(depth) + dframe_stride * (size_t)done, dstride,
+                            dframe_stride, sizeof(uint16_t), c);
+    if (st != PHOVO_OK) return st;
+    st = build_pyramids(e, first_frame + done, c, roles, kind, scale);
+    if (st != PHOVO_OK) return st;
+    // the staging buffers are reused by the next chunk and the caller's buffers may be reused on return
+    PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
+  }
+  return PHOVO_OK;
 }
 
 int phovo_engine_upload_frame(phovo_engine *e, int frame, int roles,
                               const uint8_t *intensity, size_t intensity_stride,
                               const double *depth, size_t depth_stride)
 {
-  int st = upload_common(e, frame, roles, intensity, intensity_stride);
-  if (st != PHOVO_OK) return st;
-  if (roles & PHOVO_ROLE_SOURCE) {
-    if (!depth) return fail(PHOVO_E_INVALID_ARGUMENT, "upload_frame: a source frame needs depth");
-    st = copy_rows_to_device(e->d_depth, depth, depth_stride, sizeof(double) * (size_t)e->width, e->height, e->stream);
-    if (st != PHOVO_OK) return st;
-  }
-  st = build_frame_pyramids(e, frame, roles);
-  if (st != PHOVO_OK) return st;
-  PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));     // the caller's buffers may be reused on return
-  return PHOVO_OK;
+  return upload_batch(e, frame, 1, roles, intensity, intensity_stride, 0, depth, depth_stride, 0, DEPTH_F64, 1.0);
 }
 
 int phovo_engine_upload_frame_u16(phovo_engine *e, int frame, int roles,
                                   const uint8_t *intensity, size_t intensity_stride,
                                   const uint16_t *depth, size_t depth_stride, double depth_scale)
 {
-  int st = upload_common(e, frame, roles, intensity, intensity_stride);
-  if (st != PHOVO_OK) return st;
-  if (roles & PHOVO_ROLE_SOURCE) {
-    if (!depth) return fail(PHOVO_E_INVALID_ARGUMENT, "upload_frame_u16: a source frame needs depth");
-    st = copy_rows_to_device(e->d_depth16, depth, depth_stride, sizeof(uint16_t) * (size_t)e->width, e->height, e->stream);
-    if (st != PHOVO_OK) return st;
-    PHOVO_HIP_CHECK(pyr_depth_u16_to_f64(e->d_depth16, e->width * e->height, depth_scale, e->d_depth, e->stream));
-  }
-  st = build_frame_pyramids(e, frame, roles);
-  if (st != PHOVO_OK) return st;
-  PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
-  return PHOVO_OK;
+  return upload_batch(e, frame, 1, roles, intensity, intensity_stride, 0, depth, depth_stride, 0, DEPTH_U16, depth_scale);
+}
+
+int phovo_engine_upload_frames(phovo_engine *e, int first_frame, int count, int roles,
+                               const uint8_t *intensity, size_t intensity_stride, size_t intensity_frame_stride,
+                               const double *depth, size_t depth_stride, size_t depth_frame_stride)
+{
+  return upload_batch(e, first_frame, count, roles, intensity, intensity_stride, intensity_frame_stride,
+                      depth, depth_stride, depth_frame_stride, DEPTH_F64, 1.0);
+}
+
+int phovo_engine_upload_frames_u16(phovo_engine *e, int first_frame, int count, int roles,
+                                   const uint8_t *intensity, size_t intensity_stride, size_t intensity_frame_stride,
+                                   const uint16_t *depth, size_t depth_stride, size_t depth_frame_stride,
+                                   double depth_scale)
+{
+  return upload_batch(e, first_frame, count, roles, intensity, intensity_stride, intensity_frame_stride,
+                      depth, depth_stride, depth_frame_stride, DEPTH_U16, depth_scale);
 }
 
 static int plane_access_check(const phovo_engine *e, int frame, int level)

@@ -47,15 +47,17 @@ hipError_t gn_launch_level(const GNLevelArgs &args, const GNLaunchPlan &plan, in
                            hipStream_t stream);
 hipError_t gn_prepare_kernels();   // raises the dynamic-LDS limit of every instantiation
 
-// Pyramid producers (SetSourceFrame / SetTargetFrame, ...Analytic.h:466-491).
-hipError_t pyr_intensity_level(const uint8_t *gray, int w, int h, int level, int lw, int lh,
-                               double *dst, hipStream_t stream);
-hipError_t pyr_depth_level(const double *depth, int w, int h, int level, int lw, int lh,
-                           double *dst, hipStream_t stream);
-hipError_t pyr_depth_u16_to_f64(const uint16_t *src, int n, double scale, double *dst,
-                                hipStream_t stream);
-hipError_t pyr_scharr(const double *img, int w, int h, double scale, double *gx, double *gy,
-                      hipStream_t stream);
+// Pyramid producers (SetSourceFrame / SetTargetFrame, ...Analytic.h:466-491), batched over `frames`
+// consecutive frames: frame f reads src + f*src_frame_stride and writes dst + f*dst_frame_stride (elements).
+hipError_t pyr_intensity_level(const uint8_t *gray, size_t src_frame_stride, int frames, int w, int h, int level,
+                               int lw, int lh, double *dst, size_t dst_frame_stride, hipStream_t stream);
+hipError_t pyr_depth_level(const double *depth, size_t src_frame_stride, int frames, int w, int h, int level,
+                           int lw, int lh, double *dst, size_t dst_frame_stride, hipStream_t stream);
+hipError_t pyr_depth_level_u16(const uint16_t *depth, size_t src_frame_stride, double scale, int frames, int w,
+                               int h, int level, int lw, int lh, double *dst, size_t dst_frame_stride,
+                               hipStream_t stream);
+hipError_t pyr_scharr(const double *base, size_t frame_stride, size_t img_off, size_t gx_off, size_t gy_off,
+                      int frames, int w, int h, double scale, hipStream_t stream);
 hipError_t pyr_gaussian_blur(double *img, double *tmp, int w, int h, int ksize,
                              const double *d_kernel, hipStream_t stream);
 hipError_t fill_i32(int *dst, size_t n, int value, hipStream_t stream);

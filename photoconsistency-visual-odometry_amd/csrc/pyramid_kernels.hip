@@ -19,11 +19,14 @@ namespace phovo_hip {
 
 namespace {
 
-__device__ __forceinline__ double load_px(const uint8_t *src, size_t i)
+__device__ __forceinline__ double load_px(const uint8_t *src, size_t i, double)
 {
   return (double)src[i] * (1. / 255);          // convertTo(..., 1./255)  :471,484
 }
-__device__ __forceinline__ double load_px(const double *src, size_t i) { return src[i]; }
+__device__ __forceinline__ double load_px(const double *src, size_t i, double) { return src[i]; }
+// 16-bit depth (TUM / Kinect PNG): double(u16) * scale, as `imgDepth * depthScalingFactor` does on the host
+// (apps/PhotoconsistencyVisualOdometry/PhotoconsistencyVisualOdometry.cpp:208,220)
+__device__ __forceinline__ double load_px(const uint16_t *src, size_t i, double scale) { return (double)src[i] * scale; }
 
 __device__ __forceinline__ int reflect101(int p, int len)
 {
@@ -37,21 +40,26 @@ __device__ __forceinline__ int reflect101(int p, int len)
 
 // cv::resize by 2^-level from level 0.  level 1: 2x2 area mean (((a+b)+c)+d)*0.25;
 // level >= 2: bilinear with the two central taps, weights 0.5 -- rows first, then columns.
+// blockIdx.z = frame of the batch: frame f reads src + f*src_frame_stride and writes dst + f*dst_frame_stride.
 template <typename SrcT>
-__global__ __launch_bounds__(256) void k_resize_level(const SrcT *src, int w, int h, int level,
-                                                      int lw, int lh, double *dst)
+__global__ __launch_bounds__(256) void k_resize_level(const SrcT *src_base, size_t src_frame_stride, double scl,
+                                                      int w, int h, int level, int lw, int lh,
+                                                      double *dst_base, size_t dst_frame_stride)
 {
   const int dx = blockIdx.x * blockDim.x + threadIdx.x;
   const int dy = blockIdx.y;
   if (dx >= lw || dy >= lh) return;
+  const SrcT *src = src_base + (size_t)blockIdx.z * src_frame_stride;
+  double *dst = dst_base + (size_t)blockIdx.z * dst_frame_stride;
+  auto at = [&](int y, int x) { return load_px(src, (size_t)y * w + x, scl); };
   double out;
   if (level == 0) {
-    out = load_px(src, (size_t)dy * w + dx);
+    out = at(dy, dx);
   } else if (level == 1) {
     const int sx = dx * 2, sy = dy * 2;
     if (sx + 1 < w && sy + 1 < h) {
-      const double a = load_px(src, (size_t)sy * w + sx), b = load_px(src, (size_t)sy * w + sx + 1);
-      const double c = load_px(src, (size_t)(sy + 1) * w + sx), d = load_px(src, (size_t)(sy + 1) * w + sx + 1);
+      const double a = at(sy, sx), b = at(sy, sx + 1);
+      const double c = at(sy + 1, sx), d = at(sy + 1, sx + 1);
       out = (((a + b) + c) + d) * 0.25;
     } else {
       double sum = 0; int count = 0;
@@ -59,7 +67,7 @@ __global__ __launch_bounds__(256) void k_resize_level(const SrcT *src, int w, in
         if (sy + yy >= h) break;
         for (int xx = 0; xx < 2; xx++) {
           if (sx + xx >= w) break;
-          sum += load_px(src, (size_t)(sy + yy) * w + sx + xx);
+          sum += at(sy + yy, sx + xx);
           count++;
         }
       }
@@ -72,13 +80,11 @@ __global__ __launch_bounds__(256) void k_resize_level(const SrcT *src, int w, in
     int sx = dx * s + half; double wx1 = 0.5;
     if (sx >= w - 1) { sx = w - 1; wx1 = 0.0; }
     double top, bot;
-    if (wx1 != 0.0) top = load_px(src, (size_t)sy * w + sx) * 0.5 + load_px(src, (size_t)sy * w + sx + 1) * 0.5;
-    else top = load_px(src, (size_t)sy * w + sx) * 1.0;
+    if (wx1 != 0.0) top = at(sy, sx) * 0.5 + at(sy, sx + 1) * 0.5;
+    else top = at(sy, sx) * 1.0;
     if (wy1 != 0.0) {
-      if (wx1 != 0.0)
-        bot = load_px(src, (size_t)(sy + 1) * w + sx) * 0.5 + load_px(src, (size_t)(sy + 1) * w + sx + 1) * 0.5;
-      else
-        bot = load_px(src, (size_t)(sy + 1) * w + sx) * 1.0;
+      if (wx1 != 0.0) bot = at(sy + 1, sx) * 0.5 + at(sy + 1, sx + 1) * 0.5;
+      else bot = at(sy + 1, sx) * 1.0;
       out = top * 0.5 + bot * 0.5;
     } else {
       out = top * 1.0 + top * 0.0;
@@ -87,19 +93,17 @@ __global__ __launch_bounds__(256) void k_resize_level(const SrcT *src, int w, in
   dst[(size_t)dy * lw + dx] = out;
 }
 
-__global__ __launch_bounds__(256) void k_u16_to_f64(const uint16_t *src, int n, double scale, double *dst)
-{
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[i] = (double)src[i] * scale;
-}
-
 // cv::Scharr (1,0) and (0,1), scale on the smoothing kernel, BORDER_REFLECT_101  (:181-187).
-__global__ __launch_bounds__(256) void k_scharr(const double *img, int w, int h, double scale,
-                                                double *gx, double *gy)
+// blockIdx.z = frame; the three planes of frame f sit at base + f*frame_stride + {img,gx,gy}_off.
+__global__ __launch_bounds__(256) void k_scharr(const double *base, size_t frame_stride, size_t img_off,
+                                                size_t gx_off, size_t gy_off, int w, int h, double scale)
 {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y;
   if (x >= w || y >= h) return;
+  const double *img = base + (size_t)blockIdx.z * frame_stride + img_off;
+  double *gx = const_cast<double *>(base) + (size_t)blockIdx.z * frame_stride + gx_off;
+  double *gy = const_cast<double *>(base) + (size_t)blockIdx.z * frame_stride + gy_off;
   const double k3 = 3.0 * scale, k10 = 10.0 * scale;
   const int xl = reflect101(x - 1, w), xr = reflect101(x + 1, w);
   const int yu = reflect101(y - 1, h), yd = reflect101(y + 1, h);
@@ -150,42 +154,50 @@ __global__ __launch_bounds__(256) void k_fill_i32(int *dst, size_t n, int value)
   for (; i < n; i += stride) dst[i] = value;
 }
 
-inline dim3 grid2d(int w, int h) { return dim3((unsigned)((w + 255) / 256), (unsigned)h); }
+inline dim3 grid3d(int w, int h, int frames)
+{
+  return dim3((unsigned)((w + 255) / 256), (unsigned)h, (unsigned)frames);
+}
 
 }  // namespace
 
-hipError_t pyr_intensity_level(const uint8_t *gray, int w, int h, int level, int lw, int lh,
-                               double *dst, hipStream_t stream)
+hipError_t pyr_intensity_level(const uint8_t *gray, size_t src_frame_stride, int frames, int w, int h, int level,
+                               int lw, int lh, double *dst, size_t dst_frame_stride, hipStream_t stream)
 {
-  hipLaunchKernelGGL(k_resize_level<uint8_t>, grid2d(lw, lh), dim3(256), 0, stream, gray, w, h, level, lw, lh, dst);
+  hipLaunchKernelGGL(k_resize_level<uint8_t>, grid3d(lw, lh, frames), dim3(256), 0, stream, gray, src_frame_stride,
+                     1.0, w, h, level, lw, lh, dst, dst_frame_stride);
   return hipGetLastError();
 }
 
-hipError_t pyr_depth_level(const double *depth, int w, int h, int level, int lw, int lh,
-                           double *dst, hipStream_t stream)
+hipError_t pyr_depth_level(const double *depth, size_t src_frame_stride, int frames, int w, int h, int level,
+                           int lw, int lh, double *dst, size_t dst_frame_stride, hipStream_t stream)
 {
-  hipLaunchKernelGGL(k_resize_level<double>, grid2d(lw, lh), dim3(256), 0, stream, depth, w, h, level, lw, lh, dst);
+  hipLaunchKernelGGL(k_resize_level<double>, grid3d(lw, lh, frames), dim3(256), 0, stream, depth, src_frame_stride,
+                     1.0, w, h, level, lw, lh, dst, dst_frame_stride);
   return hipGetLastError();
 }
 
-hipError_t pyr_depth_u16_to_f64(const uint16_t *src, int n, double scale, double *dst, hipStream_t stream)
+hipError_t pyr_depth_level_u16(const uint16_t *depth, size_t src_frame_stride, double scale, int frames, int w, int h,
+                               int level, int lw, int lh, double *dst, size_t dst_frame_stride, hipStream_t stream)
 {
-  hipLaunchKernelGGL(k_u16_to_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, n, scale, dst);
+  hipLaunchKernelGGL(k_resize_level<uint16_t>, grid3d(lw, lh, frames), dim3(256), 0, stream, depth, src_frame_stride,
+                     scale, w, h, level, lw, lh, dst, dst_frame_stride);
   return hipGetLastError();
 }
 
-hipError_t pyr_scharr(const double *img, int w, int h, double scale, double *gx, double *gy,
-                      hipStream_t stream)
+hipError_t pyr_scharr(const double *base, size_t frame_stride, size_t img_off, size_t gx_off, size_t gy_off,
+                      int frames, int w, int h, double scale, hipStream_t stream)
 {
-  hipLaunchKernelGGL(k_scharr, grid2d(w, h), dim3(256), 0, stream, img, w, h, scale, gx, gy);
+  hipLaunchKernelGGL(k_scharr, grid3d(w, h, frames), dim3(256), 0, stream, base, frame_stride, img_off, gx_off,
+                     gy_off, w, h, scale);
   return hipGetLastError();
 }
 
 hipError_t pyr_gaussian_blur(double *img, double *tmp, int w, int h, int ksize,
                              const double *d_kernel, hipStream_t stream)
 {
-  hipLaunchKernelGGL(k_blur_rows, grid2d(w, h), dim3(256), 0, stream, img, w, h, ksize, d_kernel, tmp);
-  hipLaunchKernelGGL(k_blur_cols, grid2d(w, h), dim3(256), 0, stream, tmp, w, h, ksize, d_kernel, img);
+  hipLaunchKernelGGL(k_blur_rows, grid3d(w, h, 1), dim3(256), 0, stream, img, w, h, ksize, d_kernel, tmp);
+  hipLaunchKernelGGL(k_blur_cols, grid3d(w, h, 1), dim3(256), 0, stream, tmp, w, h, ksize, d_kernel, img);
   return hipGetLastError();
 }
 

@@ -83,6 +83,8 @@ SYMBOLS = {
     "phovo_engine_level_is_stored": (C.c_int, [_vp, C.c_int]),
     "phovo_engine_upload_frame": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t]),
     "phovo_engine_upload_frame_u16": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, C.c_double]),
+    "phovo_engine_upload_frames": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, C.c_size_t, _vp, C.c_size_t, C.c_size_t]),
+    "phovo_engine_upload_frames_u16": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, C.c_size_t, _vp, C.c_size_t, C.c_size_t, C.c_double]),
     "phovo_engine_set_level_planes": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "phovo_engine_get_level_planes": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "phovo_engine_align_pairs": (C.c_int, [_vp, C.c_int, _ip, _ip, _vp, _vp, _vp]),

@@ -199,6 +199,25 @@ class AlignmentEngine:
             self._h, int(frame), int(roles), g.ctypes.data, g.strides[0], d.ctypes.data, d.strides[0],
             float(depth_scale)), "phovo_engine_upload_frame_u16")
 
+    def upload_frames(self, first_frame, gray, depth=None, depth_scale=None, roles=native.ROLE_BOTH):
+        """Batched upload of gray [F,H,W] u8 with depth [F,H,W] fp64 (metres) or u16 (with depth_scale)."""
+        g = np.ascontiguousarray(gray, dtype=np.uint8)
+        if g.ndim != 3:
+            raise ValueError("gray must be [frames, height, width]")
+        if depth is None:
+            check(self._lib.phovo_engine_upload_frames(self._h, int(first_frame), g.shape[0], int(roles), g.ctypes.data,
+                                                       g.strides[1], g.strides[0], None, 0, 0), "phovo_engine_upload_frames")
+        elif depth_scale is None:
+            d = np.ascontiguousarray(depth, dtype=np.float64)
+            check(self._lib.phovo_engine_upload_frames(self._h, int(first_frame), g.shape[0], int(roles), g.ctypes.data,
+                                                       g.strides[1], g.strides[0], d.ctypes.data, d.strides[1], d.strides[0]),
+                  "phovo_engine_upload_frames")
+        else:
+            d = np.ascontiguousarray(depth, dtype=np.uint16)
+            check(self._lib.phovo_engine_upload_frames_u16(self._h, int(first_frame), g.shape[0], int(roles), g.ctypes.data,
+                                                           g.strides[1], g.strides[0], d.ctypes.data, d.strides[1], d.strides[0],
+                                                           float(depth_scale)), "phovo_engine_upload_frames_u16")
+
     def set_level_planes(self, frame, level, intensity=None, depth=None, grad_x=None, grad_y=None):
         arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float64)
                 for a in (intensity, depth, grad_x, grad_y)]

@@ -358,3 +358,48 @@ def test_sequence_trajectory_matches_oracle_and_ground_truth():
     gt = se3.chain_trajectory(seq["motions"])
     ate_gt = np.sqrt(np.mean(np.sum((tg[:, :3, 3] - gt[:, :3, 3]) ** 2, axis=1)))
     assert ate_gt < 0.25
+
+
+def test_batched_upload_equals_per_frame_upload():
+    """phovo_engine_upload_frames(_u16): one copy + one producer launch per level for a whole batch must give the
+    same planes, bit for bit, as frame-by-frame uploads -- including padded rows and more frames than one chunk."""
+    F, w, h = 37, 160, 120                       # > 32: two staging chunks
+    seq = synthetic.make_sequence(2, 5, w, h, holes=0.02)
+    gray = np.stack([seq["gray"][f % 5] for f in range(F)])
+    depth = np.stack([seq["depth"][f % 5] + 0.001 * f for f in range(F)])
+    d16 = np.rint(depth * 5000.0).astype(np.uint16)
+    ncfg, _ = _cfgs(3, [1, 1, 1], [0, 0, 0])
+    with odometry.AlignmentEngine() as eng:
+        eng.set_config(ncfg)
+        eng.reserve_frames(3 * F, w, h)
+        for f in range(F):
+            eng.upload_frame(f, gray[f], depth[f])
+        eng.upload_frames(F, gray, depth)
+        # padded host layout: rows 8 bytes longer than needed, frames with a gap
+        gpad = np.zeros((F, h + 1, w + 8), dtype=np.uint8)
+        gpad[:, :h, :w] = gray
+        dpad = np.zeros((F, h + 2, w + 4), dtype=np.uint16)
+        dpad[:, :h, :w] = d16
+        import ctypes as C
+        from phovo_amd.native import check
+        check(eng._lib.phovo_engine_upload_frames_u16(
+            eng._h, 2 * F, F, native.ROLE_BOTH, gpad.ctypes.data, gpad.strides[1], gpad.strides[0],
+            dpad.ctypes.data, dpad.strides[1], dpad.strides[0], 1.0 / 5000.0), "upload_frames_u16")
+        eng2 = odometry.AlignmentEngine()
+        eng2.set_config(ncfg)
+        eng2.reserve_frames(F, w, h)
+        for f in range(F):
+            eng2.upload_frame_u16(f, gray[f], d16[f], 1.0 / 5000.0)
+        for f in (0, 1, 31, 32, 36):
+            for l in range(3):
+                a = eng.get_level_planes(f, l)
+                b = eng.get_level_planes(F + f, l)
+                c = eng.get_level_planes(2 * F + f, l)
+                d = eng2.get_level_planes(f, l)
+                for x, y in zip(a, b):
+                    np.testing.assert_array_equal(x, y)
+                for x, y in zip(c, d):
+                    np.testing.assert_array_equal(x, y)
+        eng2.close()
+        with pytest.raises(native.PhovoError):
+            eng.upload_frames(3 * F - 2, gray[:5], depth[:5])       # runs past the pool

@@ -31,13 +31,21 @@ with odometry.AlignmentEngine() as eng:
     for f in range(F):
         eng.upload_frame_u16(f, gray[f], d16[f], 1.0 / 5000.0)
     t_u16 = time.perf_counter() - t0
+    G, D16, D64 = np.stack(gray), np.stack(d16), np.stack(depth)
+    t0 = time.perf_counter()
+    eng.upload_frames(0, G, D64)
+    t_bf64 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    eng.upload_frames(0, G, D16, depth_scale=1.0 / 5000.0)
+    t_bu16 = time.perf_counter() - t0
     src, tgt = list(range(F - 1)), list(range(1, F))
     eng.align_pairs(src, tgt)
     t0 = time.perf_counter()
-    for f in range(F):
-        eng.upload_frame_u16(f, gray[f], d16[f], 1.0 / 5000.0)
+    eng.upload_frames(0, G, D16, depth_scale=1.0 / 5000.0)
     eng.align_pairs(src, tgt)
     t_e2e = time.perf_counter() - t0
 print(f"upload+pyramids fp64 depth : {F / t_f64:9.0f} frames/s  ({2.76 * F / t_f64 / 1e3:.2f} GB/s over PCIe)")
 print(f"upload+pyramids u16 depth  : {F / t_u16:9.0f} frames/s  ({0.92 * F / t_u16 / 1e3:.2f} GB/s over PCIe)")
-print(f"end-to-end sequence (u16 upload + pyramids + Optimize, shipped thresholds): {(F - 1) / t_e2e:9.0f} alignments/s")
+print(f"batched upload fp64 depth   : {F / t_bf64:9.0f} frames/s  ({2.76 * F / t_bf64 / 1e3:.2f} GB/s over PCIe)")
+print(f"batched upload u16 depth    : {F / t_bu16:9.0f} frames/s  ({0.92 * F / t_bu16 / 1e3:.2f} GB/s over PCIe)")
+print(f"end-to-end sequence (batched u16 upload + pyramids + Optimize, shipped thresholds): {(F - 1) / t_e2e:9.0f} alignments/s")
