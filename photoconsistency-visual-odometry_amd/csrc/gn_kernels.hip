@@ -236,7 +236,9 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
 
   const int tid = threadIdx.x;
   const int lane = tid & (WAVE - 1);
-  const int wave = tid / WAVE;
+  // wave-uniform by construction; saying so lets the chunk loops run on the scalar unit (s_cmp / s_cbranch)
+  // instead of exec-masked vector compares
+  const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
   const int pair = blockIdx.x;
   const int n = A.n, W = A.w, H = A.h;
 
