@@ -43,8 +43,8 @@ constexpr int NRED = 32;     // padded for the butterfly
 // Indices into the pose-constant block in LDS.
 enum {
   C_X = 0, C_Y, C_Z, C_R01, C_R02, C_R11, C_R12,
-  C_T1, C_T2, C_T3, C_T4, C_T5, C_T6, C_T8, C_T10, C_T11, C_T12, C_T13, C_T14, C_T15,
-  C_T16, C_T17, C_T18, C_T19, C_T20, C_T24, C_COUNT
+  C_T1, C_T2, C_T3, C_T4, C_T5, C_T6, C_T8, C_T11, C_T14, C_T15,
+  C_T16, C_T17, C_T24, C_CY, C_SY, C_COUNT
 };
 
 // Control words in LDS.
@@ -62,7 +62,9 @@ __device__ __forceinline__ double uniform_f64(double v)
 // Pose constants from the state: Rt (:219-241) and temp1..temp24 (:243-266), written with the
 // reference's association.  temp7 = -temp6, temp9 = -temp8, temp21 = -temp5, temp22 = temp2,
 // temp23 = temp1 hold exactly in IEEE arithmetic and are not stored; Rt(0,0) = temp15,
-// Rt(1,0) = temp14, Rt(2,0) = -temp3, Rt(2,1) = temp1, Rt(2,2) = temp2 likewise.
+// Rt(1,0) = temp14, Rt(2,0) = -temp3, Rt(2,1) = temp1, Rt(2,2) = temp2 likewise.  temp10, temp12, temp13 are
+// temp1, temp2, temp3 times cos(yaw) and temp18, temp19, temp20 the same times sin(yaw): the kernel applies
+// those two factors to the sum instead (see pass 2), so only cos(yaw) and sin(yaw) are stored.
 __device__ __forceinline__ void write_pose_constants(double x, double y, double z, double yaw, double pitch,
                                                      double roll, double *cst, int lane)
 {
@@ -87,18 +89,14 @@ __device__ __forceinline__ void write_pose_constants(double x, double y, double 
   cst[C_T5] = sp * sr * cy - cr * sy;
   cst[C_T6] = sp * sr * sy + cr * cy;
   cst[C_T8] = sr * cy - sp * cr * sy;
-  cst[C_T10] = cp * sr * cy;
   cst[C_T11] = cp * cy + x;          // the reference's bug, kept (:253)
-  cst[C_T12] = cp * cr * cy;
-  cst[C_T13] = sp * cy;
   cst[C_T14] = cp * sy;
   cst[C_T15] = cp * cy;
   cst[C_T16] = sp * sr;
   cst[C_T17] = sp * cr;
-  cst[C_T18] = cp * sr * sy;
-  cst[C_T19] = cp * cr * sy;
-  cst[C_T20] = sp * sy;
   cst[C_T24] = cp;
+  cst[C_CY] = cy;
+  cst[C_SY] = sy;
 }
 
 // One butterfly stage of the transposed wave reduction: N values in, N/2 out.  The stage is issued in
@@ -309,6 +307,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
       // software prefetch: the depth of the NEXT chunk is requested before this chunk is processed, so
       // every wave keeps a load in flight while it computes (the passes are bound by bytes in flight per CU)
       double pz_next = plane_load(rD0, k * 8);
+#pragma unroll 2
       for (int chunk = wave; chunk < A.n_chunks; chunk += NW, j++) {
         const double pz = pz_next;                                        // :279
         pz_next = plane_load(rD0, (k + NW * WAVE) * 8);                   // past the plane: 0
@@ -348,10 +347,9 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
 
     // ---- pass 2: residual, Jacobian row, normal-equation accumulation ---------------------
     const double t4 = uniform_f64(s_cst[C_T4]), t5 = uniform_f64(s_cst[C_T5]), t6 = uniform_f64(s_cst[C_T6]);
-    const double t8 = uniform_f64(s_cst[C_T8]), t10 = uniform_f64(s_cst[C_T10]), t11 = uniform_f64(s_cst[C_T11]);
-    const double t12 = uniform_f64(s_cst[C_T12]), t13 = uniform_f64(s_cst[C_T13]);
-    const double t16 = uniform_f64(s_cst[C_T16]), t17 = uniform_f64(s_cst[C_T17]), t18 = uniform_f64(s_cst[C_T18]);
-    const double t19 = uniform_f64(s_cst[C_T19]), t20 = uniform_f64(s_cst[C_T20]), t24 = uniform_f64(s_cst[C_T24]);
+    const double t8 = uniform_f64(s_cst[C_T8]), t11 = uniform_f64(s_cst[C_T11]);
+    const double t16 = uniform_f64(s_cst[C_T16]), t17 = uniform_f64(s_cst[C_T17]), t24 = uniform_f64(s_cst[C_T24]);
+    const double cosy = uniform_f64(s_cst[C_CY]), siny = uniform_f64(s_cst[C_SY]);
     const double t7 = -t6, t9 = -t8, t21 = -t5;
 
     double acc[NRED];
@@ -383,6 +381,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
         else i0_n = plane_load(rI0, o_n * 8);       // :308 of the owning source pixel (o = -1: offset past the plane -> 0)
       };
       fetch(k);
+#pragma unroll 2
       for (int chunk = wave; chunk < A.n_chunks; chunk += NW, j++) {
         const int o = o_n;
         const double pz = pz_n, gxi = gx_n, gyi = gy_n, pixel2 = i1_n, pixel1 = i0_n;
@@ -395,15 +394,20 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
           const double py = ((double)r - oy) * pz * ify;
 
           // The 2x6 warp Jacobian (:312-342) contracted with the image gradient (:348), with the common
-          // factors pulled out:  temp25 = 1/Z, temp26 = temp25^2,
-          //   Au = (pz*temp4+py*temp5+px*temp11)   [temp11 carries the reference's bug, :253]
+          // factors pulled out and the reference's temps folded by exact algebraic identities:
+          //   temp25 = 1/Zd, Zd = z+py*temp1+pz*temp2-px*temp3, temp26 = temp25^2,
+          //   Au = (pz*temp4+py*temp5+px*temp11)   [temp11 = temp15 + x carries the reference's bug, :253]
           //   Bv = (py*temp6+pz*temp9+px*temp14+y)
           //   Cm = (-py*temp16-pz*temp17-px*temp24), Dm = (py*temp22-pz*temp23)
-          //   J0 = gx*fx*temp25, J1 = gy*fy*temp25, J2 = -(gx*fx*Au + gy*fy*Bv)*temp26,
-          //   J3 = J0*(py*temp7+pz*temp8-px*temp14) + J1*(pz*temp4+py*temp5+px*temp15),
-          //   J4 = J0*(py*temp10+pz*temp12-px*temp13) + J1*(py*temp18+pz*temp19-px*temp20) + Cm*J2,
+          //   (py*temp7+pz*temp8-px*temp14) = y - Bv          since temp7 = -temp6, temp8 = -temp9
+          //   (pz*temp4+py*temp5+px*temp15) = Au - px*x       since temp15 = temp11 - x
+          //   (py*temp10+pz*temp12-px*temp13) = cos(yaw)*(Zd - z), (py*temp18+pz*temp19-px*temp20) = sin(yaw)*(Zd - z)
+          //   J0 = gx*fx*temp25, J1 = gy*fy*temp25, J2 = -(J0*Au + J1*Bv)*temp25,
+          //   J3 = J0*(y - Bv) + J1*(Au - px*x),
+          //   J4 = (J0*cos(yaw) + J1*sin(yaw))*(Zd - z) + Cm*J2,
           //   J5 = J0*(py*temp4+pz*temp21) + J1*(pz*temp7+py*temp9) + Dm*J2.
-          const double t25 = fast_rcp(cz + py * t1 + pz * t2 - px * t3);  // :313
+          const double Zr = py * t1 + pz * t2 - px * t3;                  // Zd - z
+          const double t25 = fast_rcp(cz + Zr);                           // :313
           const double Au = pz * t4 + py * t5 + px * t11;
           const double Bv = py * t6 + pz * t9 + px * t14 + cyy;
           const double Cm = -py * t16 - pz * t17 - px * t24;
@@ -412,9 +416,8 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
           J[0] = (gxi * fx) * t25;                                        // :317
           J[1] = (gyi * fy) * t25;                                        // :322
           J[2] = -(J[0] * Au + J[1] * Bv) * t25;                          // :325-326
-          J[3] = J[0] * (py * t7 + pz * t8 - px * t14) + J[1] * (pz * t4 + py * t5 + px * t15);        // :329-330
-          J[4] = J[0] * (py * t10 + pz * t12 - px * t13) + J[1] * (py * t18 + pz * t19 - px * t20)
-                 + Cm * J[2];                                                                            // :333-336
+          J[3] = J[0] * (cyy - Bv) + J[1] * (Au - px * cx);               // :329-330
+          J[4] = (J[0] * cosy + J[1] * siny) * Zr + Cm * J[2];            // :333-336
           J[5] = J[0] * (py * t4 + pz * t21) + J[1] * (pz * t7 + py * t9) + Dm * J[2];                   // :339-342
 
           int q = 0;
