@@ -529,16 +529,14 @@ size_t lds_fixed_bytes(int threads)
 }
 
 // The instantiations that exist (each one is a separate kernel in the code object):
-//   SMALL  512 threads, 2 workgroups/CU, owner map + source intensity in LDS, register mask
 //   MID    512 threads, 2 workgroups/CU, owner map in LDS, register mask
 //   WIDE   1024 threads, 1 workgroup/CU, owner map in LDS (80..160 KB), register mask
 //   HUGE   1024 threads, owner map in global memory, ballot mask in LDS
 //   TINY   256 threads, 4 workgroups/CU, everything in LDS (levels of <= 2048 pixels)
 //   QUAD   256 threads, 4 workgroups/CU, owner map in LDS, source intensity gathered from L2
-enum Variant { V_TINY = 0, V_SMALL, V_MID, V_WIDE, V_HUGE, V_QUAD };
+enum Variant { V_TINY = 0, V_MID, V_WIDE, V_HUGE, V_QUAD };
 
 #define PHOVO_KERNEL_TINY  gn_level_kernel<256, 4, true, true, true>
-#define PHOVO_KERNEL_SMALL gn_level_kernel<512, 4, true, true, true>
 #define PHOVO_KERNEL_MID   gn_level_kernel<512, 4, false, true, true>
 #define PHOVO_KERNEL_WIDE  gn_level_kernel<1024, 4, false, true, true>
 #define PHOVO_KERNEL_HUGE  gn_level_kernel<1024, 4, false, false, false>
@@ -568,11 +566,6 @@ bool gn_plan_level(int n, GNLaunchPlan *plan)
   }
   const size_t f512 = lds_fixed_bytes(512), f1024 = lds_fixed_bytes(1024);
   const bool reg512 = n_chunks <= 64 * 8, reg1024 = n_chunks <= 64 * 16;
-  if (reg512 && f512 + owner + src <= LDS_HALF) {
-    plan->variant = V_SMALL; plan->threads = 512; plan->owner_in_lds = true; plan->source_in_lds = true;
-    plan->lds_bytes = (int)(f512 + owner + src);
-    return true;
-  }
   static const bool force_wide = std::getenv("PHOVO_GN_FORCE_WIDE") != nullptr;     // tuning aid
   if (!force_wide && reg512 && f512 + owner <= LDS_HALF) {
     plan->variant = V_MID; plan->threads = 512; plan->owner_in_lds = true; plan->source_in_lds = false;
@@ -599,7 +592,6 @@ hipError_t gn_prepare_kernels()
                           (int)LDS_LIMIT);                                                        \
   if (e != hipSuccess) return e;
   PHOVO_PREP(PHOVO_KERNEL_TINY)
-  PHOVO_PREP(PHOVO_KERNEL_SMALL)
   PHOVO_PREP(PHOVO_KERNEL_MID)
   PHOVO_PREP(PHOVO_KERNEL_WIDE)
   PHOVO_PREP(PHOVO_KERNEL_HUGE)
@@ -616,7 +608,6 @@ hipError_t gn_launch_level(const GNLevelArgs &a, const GNLaunchPlan &plan, int n
   const dim3 grid((unsigned)n_pairs), block((unsigned)plan.threads);
   switch (plan.variant) {
     case V_TINY:  hipLaunchKernelGGL(PHOVO_KERNEL_TINY, grid, block, lds, stream, a); break;
-    case V_SMALL: hipLaunchKernelGGL(PHOVO_KERNEL_SMALL, grid, block, lds, stream, a); break;
     case V_MID:   hipLaunchKernelGGL(PHOVO_KERNEL_MID, grid, block, lds, stream, a); break;
     case V_WIDE:  hipLaunchKernelGGL(PHOVO_KERNEL_WIDE, grid, block, lds, stream, a); break;
     case V_HUGE:  hipLaunchKernelGGL(PHOVO_KERNEL_HUGE, grid, block, lds, stream, a); break;

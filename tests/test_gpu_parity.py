@@ -403,3 +403,33 @@ def test_batched_upload_equals_per_frame_upload():
         eng2.close()
         with pytest.raises(native.PhovoError):
             eng.upload_frames(3 * F - 2, gray[:5], depth[:5])       # runs past the pool
+
+
+@pytest.mark.parametrize("size,expect", [
+    ((40, 30), dict(threads=256, owner_in_lds=True, source_in_lds=True)),       # TINY: everything in LDS
+    ((80, 60), dict(threads=256, owner_in_lds=True, source_in_lds=False)),      # QUAD: 4 workgroups per CU
+    ((160, 120), dict(threads=512, owner_in_lds=True, source_in_lds=False)),    # MID: 2 workgroups per CU
+    ((200, 152), dict(threads=1024, owner_in_lds=True, source_in_lds=False)),   # WIDE: one 1024-thread workgroup
+    ((320, 240), dict(threads=1024, owner_in_lds=False, source_in_lds=False)),  # HUGE: owner map in HBM
+])
+def test_every_kernel_variant_matches_oracle(size, expect):
+    """One single-level problem per launch geometry of gn_plan_level, each checked against the oracle."""
+    w, h = size
+    p = synthetic.make_pair(13, w, h, holes=0.03, trans=0.01 * w / 640, rot=0.004)
+    ncfg, ocfg = _cfgs(1, [7], [0.0])
+    es, eits, etr = oracle.align_frames(ocfg, p["K"], p["gray0"], p["depth0"], p["gray1"], want_trace=True)
+    with odometry.AlignmentEngine() as eng:
+        eng.set_config(ncfg)
+        eng.set_intrinsic_matrix(p["K"])
+        eng.reserve_frames(2, w, h)
+        info = eng.level_launch_info(0)
+        for k, v in expect.items():
+            assert info[k] == v, (k, info)
+        eng.upload_frame(0, p["gray0"], p["depth0"], roles=native.ROLE_SOURCE)
+        eng.upload_frame(1, p["gray1"], None, roles=native.ROLE_TARGET)
+        s, reps = eng.align_pairs([0, 0, 0], [1, 1, 1], want_reports=True)
+    assert list(reps[0].iterations[:1]) == eits
+    assert se3.state_distance(s[0], es) < POSE_TOL
+    assert np.array_equal(s[0], s[1]) and np.array_equal(s[0], s[2])
+    g_last = np.linalg.norm(etr[-1]["gradient"])
+    assert abs(reps[0].gradient_norm - g_last) <= 1e-9 * max(1.0, g_last)
