@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--pairs", type=int, default=2048, help="frame pairs per GPU per step")
     ap.add_argument("--distinct", type=int, default=32, help="distinct synthetic pairs generated per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="bound of the CPU-oracle baseline sample")
+    ap.add_argument("--cpu-threads", type=int, default=16,
+                    help="threads of the all-cores CPU baseline (a one-GPU box's CPU share); 1 = skip it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-termination", action="store_true")
     return ap.parse_args()
@@ -168,13 +170,16 @@ def main():
                     all_levels_achieved=total_bytes / (total_ms * 1e-3) / 1e9,
                     all_levels_frac=total_bytes / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     levels=levels_out)
+    # HBM bytes per launch of the dominant kernel from the PMC counters: collected in separate rocprofv3 --pmc
+    # passes of this same command and calibrated (profiles/README.md); cannot be measured from inside the run.
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            t = json.load(open(pmc))
-            if t.get("pairs") == n_local and t.get("level") == dom["level"]:
-                roofline["traffic"] = t["hbm_bytes_per_launch"]
-                roofline["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc, separate run)"
+            for kd in json.load(open(pmc)).get("kernels", []):
+                if kd.get("threads") == dom["threads"] and kd.get("pairs") == n_local:
+                    roofline["traffic"] = kd["hbm_bytes_per_launch"]
+                    roofline["traffic_over_algorithmic"] = kd["hbm_bytes_per_launch"] / dom["algorithmic_bytes"]
+                    roofline["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, calibrated)"
         except Exception:
             pass
 
@@ -193,9 +198,15 @@ def main():
             wall2 = float(tmax.item())
         _, reps2 = eng.fetch_results(n_local, want_reports=True)
         it2 = np.array([list(r.iterations[:nl]) for r in reps2])
+        hist = {}
+        for l in range(nl):
+            if max_iter[l] > 0:                  # iterations executed -> number of pairs (this rank's pairs)
+                vals, counts = np.unique(it2[:, l], return_counts=True)
+                hist[f"level_{l}"] = {int(v): int(c) for v, c in zip(vals, counts)}
         ref_term = dict(value=n_global * k2 / wall2, unit="alignments/s", steps=k2,
                         mean_iterations_per_level=[float(x) for x in it2.mean(axis=0)],
-                        max_iterations_per_level=[int(x) for x in it2.max(axis=0)])
+                        max_iterations_per_level=[int(x) for x in it2.max(axis=0)],
+                        iteration_histogram=hist)
 
     # ---- CPU baseline: the oracle, one thread, bounded sample of the same workload ------------
     cpu = None
@@ -215,6 +226,33 @@ def main():
                    sample=f"{done} alignments over the same synthetic 640x480 pairs, fixed-iteration mode, Optimize() only "
                           f"({t_cpu:.1f} s, gcc -O3 -mtune=native, single thread as the reference builds)",
                    host_cpus=os.cpu_count())
+
+    # the same oracle on the GPU box's CPU share (16 threads for one GPU), independent pairs per thread
+    cpu_all = None
+    if cpu is not None and args.cpu_threads > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        from oracle import oracle
+        ocfg = oracle.make_config(num_levels=nl, max_iter=max_iter, min_grad=[0.0] * nl)
+        pyr = []
+        for t in range(min(distinct, args.cpu_threads)):
+            i0p, d0p = oracle.build_source_pyramids(seq["gray"][t], seq["depth"][t], ocfg)
+            i1p, gxp, gyp = oracle.build_target_pyramids(seq["gray"][t + 1], ocfg)
+            pyr.append((i0p, d0p, i1p, gxp, gyp))
+        budget = args.cpu_seconds
+
+        def worker(i):
+            n_done, t_end = 0, time.perf_counter() + budget
+            while time.perf_counter() < t_end:
+                oracle.optimize(ocfg, seq["K"], *pyr[i % len(pyr)])       # ctypes releases the GIL
+                n_done += 1
+            return n_done
+        c0 = time.perf_counter()
+        with ThreadPoolExecutor(args.cpu_threads) as ex:
+            total = sum(ex.map(worker, range(args.cpu_threads)))
+        wall_cpu = time.perf_counter() - c0
+        cpu_all = dict(value=total / wall_cpu, unit="alignments/s", cores=args.cpu_threads, kind="port",
+                       sample=f"{total} alignments, {args.cpu_threads} threads x {budget:.0f} s, independent pairs per "
+                              f"thread, fixed-iteration mode, Optimize() only")
 
     if rank == 0:
         out = {
@@ -244,6 +282,7 @@ def main():
                 level_sizes, [m if max_iter[l] > 0 else 0.0 for l, m in enumerate(iters.mean(axis=0))]) / 1e6,
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "cpu_baseline_all_cores": cpu_all,
             "reference_termination": ref_term,
         }
         print(json.dumps(out))

@@ -62,7 +62,14 @@ def main():
                                    FETCH_SIZE_KB=v, WRITE_SIZE_KB=w,
                                    hbm_read_bytes=v * 1024.0 * ff, hbm_write_bytes=w * 1024.0 * wf,
                                    hbm_bytes_per_launch=v * 1024.0 * ff + w * 1024.0 * wf))
+    import re
+    for kd in out["kernels"]:
+        m = re.search(r"gn_level_kernel<(\d+)", kd["kernel"])
+        kd["threads"] = int(m.group(1)) if m else None
+        kd["pairs"] = kd["grid_size"] // kd["threads"] if kd["threads"] else None
     json.dump(out, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+    if len(sys.argv) > 4 and sys.argv[4] == "--current":      # the file bench.py reads for roofline.traffic
+        json.dump(out, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 
