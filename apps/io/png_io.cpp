@@ -68,6 +68,11 @@ bool load(const std::string &path, Raw *raw, std::string *err)
   }
   const size_t bpp = (size_t)raw->channels * raw->bit_depth / 8;
   const size_t stride = bpp * (size_t)raw->width;
+  // a header can claim any size: refuse what no camera produces before allocating for it
+  if (raw->width > 65535 || raw->height > 65535 || (stride + 1) * (size_t)raw->height > ((size_t)1 << 30)) {
+    *err = path + ": image dimensions out of range";
+    return false;
+  }
   std::vector<uint8_t> infl((stride + 1) * (size_t)raw->height);
   uLongf out_len = (uLongf)infl.size();
   if (uncompress(infl.data(), &out_len, idat.data(), (uLong)idat.size()) != Z_OK || out_len != infl.size()) {

@@ -1,0 +1,98 @@
+"""Native (non-Python) clients of the boundary, CPU only:
+  * a C11 program compiled with gcc against include/phovo_hip.h and linked to libphovo_hip.so,
+  * AddressSanitizer / UBSan builds of the host-side parsers (yml reader, PNG codec) on good and hostile input
+    (GPU sanitizers are not available on the pool; the CPU build is what can be sanitised)."""
+import os
+import struct
+import subprocess
+import zlib
+
+import pytest
+
+import phovo_amd  # noqa: F401
+from phovo_amd import native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = os.path.join(ROOT, "config_files")
+PKG = os.path.dirname(native.library_path())
+
+
+def test_header_is_valid_c_and_c_client_runs(tmp_path):
+    native.lib()
+    exe = tmp_path / "cabi_c_client"
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "native", "cabi_c_client.c"), "-o", str(exe),
+                           "-L", PKG, "-lphovo_hip", "-lm", f"-Wl,-rpath,{PKG}", "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([str(exe), os.path.join(CFG, "config_4_level_optimization_analytic.yml")],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "cabi_c_client ok" in r.stdout
+
+
+def test_yml_reader_under_asan_ubsan(tmp_path):
+    exe = tmp_path / "yml_asan"
+    csrc = os.path.join(ROOT, "photoconsistency-visual-odometry_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", csrc, "-I", "/opt/rocm/include",
+                           os.path.join(csrc, "yml_config.cpp"), os.path.join(ROOT, "tests", "native", "yml_asan_driver.cpp"),
+                           "-o", str(exe)])
+    good = [os.path.join(CFG, f) for f in sorted(os.listdir(CFG))]
+    r = subprocess.run([str(exe)] + good, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    hostile = {
+        "empty.yml": "",
+        "nolevels.yml": "%YAML:1.0\nblurFilterSize (at each level): [0]\n",
+        "huge.yml": "%YAML:1.0\nnumOptimizationLevels: 999999999999\n",
+        "unterminated.yml": "%YAML:1.0\nnumOptimizationLevels: 2\nblurFilterSize (at each level): [0, 0\n",
+        "garbage.yml": "%YAML:1.0\nnumOptimizationLevels: two\n: : :\n[[[[\n" + "x" * 100000 + "\n",
+        "long_seq.yml": "%YAML:1.0\nnumOptimizationLevels: 2\nblurFilterSize (at each level): [" + ",".join(["1"] * 5000) + "]\n"
+                        "imageGradientsScalingFactor (at each level): [1,1]\nlambda_optimization_step (at each level): [1,1]\n"
+                        "max_num_iterations (at each level): [1,1]\nmin_gradient_norm (at each level): [1,1]\nvisualizeIterations: 0\n",
+        "nan.yml": "%YAML:1.0\nnumOptimizationLevels: nan\n",
+    }
+    paths = []
+    for name, text in hostile.items():
+        (tmp_path / name).write_text(text)
+        paths.append(str(tmp_path / name))
+    r = subprocess.run([str(exe)] + paths, capture_output=True, text=True, timeout=120)
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr
+    # every hostile file is rejected with a status, except the over-long sequence, which is legal
+    lines = [l for l in r.stdout.splitlines() if "->" in l]
+    status = {os.path.basename(l.split(" -> ")[0]): int(l.split(" -> ")[1].split()[0]) for l in lines}
+    assert status["long_seq.yml"] == 0
+    assert all(v != 0 for k, v in status.items() if k != "long_seq.yml"), status
+
+
+def test_png_codec_under_asan_ubsan(tmp_path):
+    exe = tmp_path / "png_asan"
+    apps = os.path.join(ROOT, "apps")
+    subprocess.check_call(["g++", "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-I", apps, os.path.join(apps, "tools", "png_probe.cpp"), os.path.join(apps, "io", "png_io.cpp"),
+                           "-o", str(exe), "-lz"])
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    sig = b"\x89PNG\r\n\x1a\n"
+    ihdr = lambda w, h, bd, ct, il=0: chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, bd, ct, 0, 0, il))
+    good_raw = b"".join(b"\x00" + bytes(range(8)) for _ in range(4))
+    files = {
+        "ok.png": sig + ihdr(8, 4, 8, 0) + chunk(b"IDAT", zlib.compress(good_raw)) + chunk(b"IEND", b""),
+        "truncated_idat.png": sig + ihdr(8, 4, 8, 0) + chunk(b"IDAT", zlib.compress(good_raw)[:5]) + chunk(b"IEND", b""),
+        "short_data.png": sig + ihdr(64, 64, 8, 0) + chunk(b"IDAT", zlib.compress(good_raw)) + chunk(b"IEND", b""),
+        "huge_dims.png": sig + ihdr(0x7fffffff, 2, 16, 6) + chunk(b"IDAT", zlib.compress(b"\x00")) + chunk(b"IEND", b""),
+        "bad_filter.png": sig + ihdr(8, 1, 8, 0) + chunk(b"IDAT", zlib.compress(b"\x09" + bytes(8))) + chunk(b"IEND", b""),
+        "interlaced.png": sig + ihdr(8, 4, 8, 0, 1) + chunk(b"IDAT", zlib.compress(good_raw)) + chunk(b"IEND", b""),
+        "chunk_overrun.png": sig + struct.pack(">I", 0xfffffff0) + b"IDAT" + b"\x00" * 16,
+        "palette_oob.png": sig + ihdr(4, 1, 8, 3) + chunk(b"PLTE", b"\x01\x02\x03") + chunk(b"IDAT", zlib.compress(b"\x00\x00\x01\x02\x03")) + chunk(b"IEND", b""),
+        "no_ihdr.png": sig + chunk(b"IDAT", zlib.compress(good_raw)) + chunk(b"IEND", b""),
+    }
+    for name, data in files.items():
+        (tmp_path / name).write_bytes(data)
+        for mode in ("gray8", "raw16"):
+            r = subprocess.run([str(exe), mode, str(tmp_path / name), str(tmp_path / "out.raw")],
+                               capture_output=True, text=True, timeout=60)
+            assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, (name, mode, r.stderr[-2000:])
+            if name == "ok.png":
+                assert r.returncode == 0, r.stderr
+            else:
+                assert r.returncode == 1, (name, mode, r.returncode, r.stderr)
