@@ -70,6 +70,24 @@ typedef struct phovo_pair_report {
   uint32_t reserved;
 } phovo_pair_report;
 
+/* ---- extensions that are NOT in the reference (BASELINE.json configs[4]); all off by default -------------
+ * plane_storage: how the pyramid planes are kept in HBM.  Arithmetic is fp64 in every mode; pyramids are built
+ * in fp64 and rounded once when stored (fp64 -> fp32 by round-to-nearest-even, fp16 via fp32).
+ *   PHOVO_STORAGE_F64  reference-exact (cv::Mat_<double>, ...Analytic.h:73-85)
+ *   PHOVO_STORAGE_F32  all four planes fp32  (half the HBM footprint and traffic)
+ *   PHOVO_STORAGE_F16  intensity and gradients fp16, depth fp32  (10 instead of 32 bytes per pixel)
+ * huber_delta[L] > 0 turns the least-squares step of level L into an IRLS step of the Huber loss: residual k gets
+ * the weight 1 if |r_k| <= delta, delta/|r_k| otherwise, in both J^T W J and J^T W r (and hence in the gradient norm
+ * of the termination test).  <= 0: off. */
+#define PHOVO_STORAGE_F64 0
+#define PHOVO_STORAGE_F32 1
+#define PHOVO_STORAGE_F16 2
+typedef struct phovo_extensions {
+  int    plane_storage;                     /* PHOVO_STORAGE_*                                            */
+  int    reserved;
+  double huber_delta[PHOVO_MAX_LEVELS];     /* optional yml key "huber_delta (at each level)"             */
+} phovo_extensions;
+
 typedef struct phovo_engine phovo_engine;
 typedef struct phovo_odometry phovo_odometry;
 
@@ -87,6 +105,12 @@ int phovo_config_default(phovo_config *cfg);
  * keys with spaces and parentheses, per-level arrays that may be longer than num_levels). */
 int phovo_config_read_file(const char *path, phovo_config *cfg);
 
+int phovo_extensions_default(phovo_extensions *ext);
+/* Optional keys in the same yml file (the reference's cv::FileStorage lookups ignore keys they do not ask for,
+ * so such a file still loads there): "huber_delta (at each level): [..]", "plane_storage_bits: 64|32|16".
+ * Absent keys leave the defaults (everything off). */
+int phovo_extensions_read_file(const char *path, phovo_extensions *ext);
+
 /* eigenPose, CPhotoconsistencyOdometry.h:47-71: (x,y,z,yaw,pitch,roll) -> row-major 4x4. */
 int phovo_eigen_pose(const double state[6], double rt[16]);
 
@@ -95,6 +119,7 @@ int phovo_odometry_create(int device, phovo_odometry **out);               /* ct
 int phovo_odometry_destroy(phovo_odometry *o);                             /* dtor  :445     */
 int phovo_odometry_read_configuration_file(phovo_odometry *o, const char *path);   /* :581 */
 int phovo_odometry_set_config(phovo_odometry *o, const phovo_config *cfg);
+int phovo_odometry_set_extensions(phovo_odometry *o, const phovo_extensions *ext);   /* not in the reference */
 int phovo_odometry_set_min_depth(phovo_odometry *o, double min_depth);     /* :448 */
 int phovo_odometry_set_max_depth(phovo_odometry *o, double max_depth);     /* :454 */
 int phovo_odometry_set_intrinsic_matrix(phovo_odometry *o, const double k[9]);     /* :460, row-major 3x3 */
@@ -126,6 +151,9 @@ int phovo_engine_create(int device, phovo_engine **out);
 int phovo_engine_destroy(phovo_engine *e);
 int phovo_engine_set_config(phovo_engine *e, const phovo_config *cfg);
 int phovo_engine_get_config(const phovo_engine *e, phovo_config *cfg);
+/* Changing plane_storage drops the frame pool (like a configuration that changes the levels). */
+int phovo_engine_set_extensions(phovo_engine *e, const phovo_extensions *ext);
+int phovo_engine_get_extensions(const phovo_engine *e, phovo_extensions *ext);
 int phovo_engine_set_intrinsic_matrix(phovo_engine *e, const double k[9]);
 int phovo_engine_set_depth_range(phovo_engine *e, double min_depth, double max_depth);
 /* 0 (default): only levels with max_num_iterations > 0 are built and kept in HBM (the others are
@@ -158,8 +186,9 @@ int phovo_engine_upload_frames_u16(phovo_engine *e, int first_frame, int count, 
                                    const uint8_t *intensity, size_t intensity_stride, size_t intensity_frame_stride,
                                    const uint16_t *depth, size_t depth_stride, size_t depth_frame_stride,
                                    double depth_scale);
-/* Direct access to the fp64 planes of one level of one frame (w*h doubles each, NULL = skip):
- * lets a caller supply pyramids built elsewhere (e.g. by OpenCV) or read back the device-built ones. */
+/* Direct access to the planes of one level of one frame as fp64 (w*h doubles each, NULL = skip): lets a
+ * caller supply pyramids built elsewhere (e.g. by OpenCV) or read back the device-built ones.  With a narrower
+ * plane_storage, set rounds to the storage type and get returns the stored (rounded) values. */
 int phovo_engine_set_level_planes(phovo_engine *e, int frame, int level,
                                   const double *intensity, const double *depth,
                                   const double *grad_x, const double *grad_y);

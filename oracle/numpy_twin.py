@@ -147,7 +147,8 @@ def normal_equations(planes, level, K, state, min_depth=0.3, max_depth=5.0):
 
 
 def optimize(pyr, K, cfg, init_state=None):
-    """cfg: dict(num_levels, lam, max_iter, min_grad, min_depth, max_depth).
+    """cfg: dict(num_levels, lam, max_iter, min_grad, min_depth, max_depth[, huber_delta]).
+    huber_delta[L] > 0 (extension, not in the reference): IRLS weights of the Huber loss.
     Returns (state, iterations_per_level, trace list)."""
     state = np.zeros(6) if init_state is None else np.array(init_state, dtype=np.float64)
     g = np.zeros(6)
@@ -157,8 +158,14 @@ def optimize(pyr, K, cfg, init_state=None):
         it = 0
         while True:
             if cfg["max_iter"][level] > 0:
-                g, Hm, _, _ = normal_equations(pyr[level], level, K, state,
+                g, Hm, r, J = normal_equations(pyr[level], level, K, state,
                                                cfg.get("min_depth", 0.3), cfg.get("max_depth", 5.0))
+                delta = cfg.get("huber_delta", [0.0] * cfg["num_levels"])[level]
+                if delta > 0:
+                    ar = np.abs(r)
+                    wgt = np.where(ar <= delta, 1.0, delta / np.maximum(ar, 1e-300))
+                    g = J.T @ (wgt * r)
+                    Hm = J.T @ (J * wgt[:, None])
                 state = state - cfg["lam"][level] * np.linalg.solve(Hm, g)
                 trace.append(dict(level=level, iteration=it + 1, gradient=g.copy(),
                                   hessian=Hm.copy(), state=state.copy()))

@@ -398,10 +398,37 @@ static void inverse6(const double a[36], double inv[36])
 /* ------------------------------------------------------------------------- */
 /* Optimize: ...Analytic.h:500-563, TestTerminationCriteria :376-392          */
 /* ------------------------------------------------------------------------- */
+static int optimize_impl(const phovo_oracle_config *cfg, const double k[9],
+                         const phovo_oracle_level *levels, double state[6],
+                         int *iterations_per_level,
+                         phovo_oracle_trace_entry *trace, int trace_capacity,
+                         const double *huber_delta);
+
 int phovo_oracle_optimize(const phovo_oracle_config *cfg, const double k[9],
                           const phovo_oracle_level *levels, double state[6],
                           int *iterations_per_level,
                           phovo_oracle_trace_entry *trace, int trace_capacity)
+{
+  return optimize_impl(cfg, k, levels, state, iterations_per_level, trace, trace_capacity, NULL);
+}
+
+/* EXTENSION, NOT IN THE REFERENCE (BASELINE.json configs[4]): Optimize() with Huber IRLS weights.  Row k of the
+ * normal equations gets w_k = 1 if |r_k| <= delta_L, delta_L/|r_k| otherwise: g = J^T W r, H = J^T W J.
+ * huber_delta[L] <= 0 leaves level L exactly as the reference.  Used only to check the device extension. */
+int phovo_oracle_optimize_huber(const phovo_oracle_config *cfg, const double k[9],
+                                const phovo_oracle_level *levels, double state[6],
+                                int *iterations_per_level,
+                                phovo_oracle_trace_entry *trace, int trace_capacity,
+                                const double *huber_delta)
+{
+  return optimize_impl(cfg, k, levels, state, iterations_per_level, trace, trace_capacity, huber_delta);
+}
+
+static int optimize_impl(const phovo_oracle_config *cfg, const double k[9],
+                         const phovo_oracle_level *levels, double state[6],
+                         int *iterations_per_level,
+                         phovo_oracle_trace_entry *trace, int trace_capacity,
+                         const double *huber_delta)
 {
   double gradients[6] = {0, 0, 0, 0, 0, 0};    /* m_Gradients persists across levels */
   int executed = 0;
@@ -423,6 +450,18 @@ int phovo_oracle_optimize(const phovo_oracle_config *cfg, const double k[9],
             cfg->min_depth, cfg->max_depth, residuals, jacobians, NULL);
 
         double H[36];
+        const double delta = huber_delta ? huber_delta[level] : 0.0;
+        if (delta > 0.0) {        /* extension: scale row k of J by w_k once; J^T (W r) and (W J)^T J follow */
+          for (size_t i = 0; i < nPoints; i++) {
+            const double ar = fabs(residuals[i]);
+            const double wgt = ar <= delta ? 1.0 : delta / ar;
+            if (wgt != 1.0) {
+              /* keep an unweighted copy in the residual's place is not needed: g uses w*J*r, H uses w*J*J */
+              for (int a = 0; a < 6; a++) jacobians[(size_t)a * nPoints + i] *= sqrt(wgt);
+              residuals[i] *= sqrt(wgt);
+            }
+          }
+        }
         for (int a = 0; a < 6; a++) {                                   /* J^T r  :538 */
           const double *ja = jacobians + (size_t)a * nPoints;
           double s = 0;

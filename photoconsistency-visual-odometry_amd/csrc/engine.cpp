@@ -31,7 +31,9 @@ int fail(int status, const std::string &msg) { g_last_error = msg; return status
 struct LevelPool {
   int w = 0, h = 0, n = 0;
   bool stored = false;
-  double *planes = nullptr;      // [frames][4][n]
+  unsigned char *planes = nullptr;   // frame f at planes + f*frame_bytes, plane p of it at + plane_off[p]
+  size_t frame_bytes = 0;
+  size_t plane_off[PLANES_PER_FRAME] = {0, 0, 0, 0};
   GNLaunchPlan plan{};
   bool plan_ok = false;
 };
@@ -49,6 +51,7 @@ struct phovo_engine {
   bool have_timing = false;
 
   phovo_config cfg{};
+  phovo_extensions ext{};                      // plane storage, Huber deltas: all off by default
   double K[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   bool have_K = false;
   double min_depth = 0.3, max_depth = 5.0;     // ...Analytic.h:430
@@ -63,6 +66,7 @@ struct phovo_engine {
   double *d_depth = nullptr;
   uint16_t *d_depth16 = nullptr;
   double *d_tmp = nullptr;
+  double *d_scratch = nullptr;                 // fp64 planes of one staging chunk (narrow storages, plane get/set)
   double *d_blur_kernel = nullptr;             // [levels][max ksize]
   int blur_kernel_stride = 0;
 
@@ -88,6 +92,8 @@ void free_pool(phovo_engine *e)
   if (e->d_depth16) (void)hipFree(e->d_depth16);
   if (e->d_tmp) (void)hipFree(e->d_tmp);
   if (e->d_blur_kernel) (void)hipFree(e->d_blur_kernel);
+  if (e->d_scratch) (void)hipFree(e->d_scratch);
+  e->d_scratch = nullptr;
   e->d_gray = nullptr; e->d_depth = nullptr; e->d_depth16 = nullptr; e->d_tmp = nullptr;
   e->d_blur_kernel = nullptr;
   e->stage_frames = 0; e->stage_has_f64 = e->stage_has_u16 = false;
@@ -174,11 +180,16 @@ int build_pyramids(phovo_engine *e, int first_frame, int count, int roles, Depth
 {
   const int w = e->width, h = e->height;
   const size_t px = (size_t)w * (size_t)h;
+  const int storage = e->ext.plane_storage;
   for (int l = 0; l < e->cfg.num_levels; l++) {
     LevelPool &lv = e->levels[l];
     if (!lv.stored) continue;
+    // fp64 storage: the producers write straight into the pool.  Narrow storage: they write fp64 planes into
+    // the scratch chunk (same [frame][4][n] layout) and a convert pass rounds them into the pool once.
     const size_t fstride = (size_t)PLANES_PER_FRAME * (size_t)lv.n;
-    double *base = lv.planes + (size_t)first_frame * fstride;
+    double *base = storage == PHOVO_STORAGE_F64
+                       ? reinterpret_cast<double *>(lv.planes + (size_t)first_frame * lv.frame_bytes)
+                       : e->d_scratch;
     // BuildPyramid(intensity, applyBlur = true)  :474,487
     PHOVO_HIP_CHECK(pyr_intensity_level(e->d_gray, px, count, w, h, l, lv.w, lv.h,
                                         base + (size_t)PLANE_I * lv.n, fstride, e->stream));
@@ -202,6 +213,16 @@ int build_pyramids(phovo_engine *e, int first_frame, int count, int roles, Depth
       PHOVO_HIP_CHECK(pyr_scharr(base, fstride, (size_t)PLANE_I * lv.n, (size_t)PLANE_GX * lv.n,
                                  (size_t)PLANE_GY * lv.n, count, lv.w, lv.h,
                                  e->cfg.image_gradients_scaling_factor[l], e->stream));
+    if (storage != PHOVO_STORAGE_F64) {
+      unsigned char *dst = lv.planes + (size_t)first_frame * lv.frame_bytes;
+      const bool want[PLANES_PER_FRAME] = {true, (roles & PHOVO_ROLE_SOURCE) != 0, (roles & PHOVO_ROLE_TARGET) != 0,
+                                           (roles & PHOVO_ROLE_TARGET) != 0};
+      for (int p = 0; p < PLANES_PER_FRAME; p++) {
+        if (!want[p]) continue;
+        PHOVO_HIP_CHECK(pyr_store_plane(base + (size_t)p * lv.n, fstride, count, lv.n, dst + lv.plane_off[p],
+                                        lv.frame_bytes, storage, p == PLANE_D, e->stream));
+      }
+    }
   }
   return PHOVO_OK;
 }
@@ -306,6 +327,7 @@ int phovo_engine_create(int device, phovo_engine **out)
   if (!e) return fail(PHOVO_E_INVALID_ARGUMENT, "out of host memory");
   e->device = device;
   phovo_config_default(&e->cfg);
+  phovo_extensions_default(&e->ext);
   hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
   if (he == hipSuccess) {
     for (int l = 0; l < PHOVO_MAX_LEVELS && he == hipSuccess; l++) {
@@ -356,6 +378,40 @@ int phovo_engine_set_config(phovo_engine *e, const phovo_config *cfg)
   (void)hipStreamSynchronize(e->stream);
   if (!keep) free_pool(e);
   e->cfg = *cfg;
+  return PHOVO_OK;
+}
+
+int phovo_extensions_default(phovo_extensions *ext)
+{
+  if (!ext) return fail(PHOVO_E_INVALID_ARGUMENT, "phovo_extensions_default: null");
+  std::memset(ext, 0, sizeof(*ext));
+  ext->plane_storage = PHOVO_STORAGE_F64;
+  return PHOVO_OK;
+}
+
+int phovo_extensions_read_file(const char *path, phovo_extensions *ext) { return read_extensions_file(path, ext); }
+
+int phovo_engine_set_extensions(phovo_engine *e, const phovo_extensions *ext)
+{
+  if (!e || !ext) return fail(PHOVO_E_INVALID_ARGUMENT, "set_extensions: null");
+  if (ext->plane_storage != PHOVO_STORAGE_F64 && ext->plane_storage != PHOVO_STORAGE_F32 &&
+      ext->plane_storage != PHOVO_STORAGE_F16)
+    return fail(PHOVO_E_INVALID_ARGUMENT, "set_extensions: unknown plane_storage");
+  for (int l = 0; l < PHOVO_MAX_LEVELS; l++)
+    if (!(ext->huber_delta[l] == ext->huber_delta[l])) return fail(PHOVO_E_INVALID_ARGUMENT, "set_extensions: huber_delta is NaN");
+  if (ext->plane_storage != e->ext.plane_storage) {      // the pool layout changes
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    free_pool(e);
+  }
+  e->ext = *ext;
+  return PHOVO_OK;
+}
+
+int phovo_engine_get_extensions(const phovo_engine *e, phovo_extensions *ext)
+{
+  if (!e || !ext) return fail(PHOVO_E_INVALID_ARGUMENT, "get_extensions: null");
+  *ext = e->ext;
   return PHOVO_OK;
 }
 
@@ -410,8 +466,19 @@ int phovo_engine_reserve_frames(phovo_engine *e, int n_frames, int width, int he
     lv.n = lv.w * lv.h;
     lv.stored = e->build_all || e->cfg.max_num_iterations[l] > 0;
     lv.plan_ok = gn_plan_level(lv.n, &lv.plan);
+    {   // byte layout of one frame at this level: planes I, D, GX, GY.  fp64: packed [4][n] doubles, which is
+        // what the producer kernels write directly; narrow storages: every plane starts 16-byte aligned.
+      const bool packed = e->ext.plane_storage == PHOVO_STORAGE_F64;
+      size_t off = 0;
+      for (int p = 0; p < PLANES_PER_FRAME; p++) {
+        lv.plane_off[p] = off;
+        const size_t bytes = storage_elem_size(e->ext.plane_storage, p == PLANE_D) * (size_t)lv.n;
+        off += packed ? bytes : ((bytes + 15) & ~(size_t)15);
+      }
+      lv.frame_bytes = off;
+    }
     if (lv.stored) {
-      const size_t bytes = sizeof(double) * (size_t)n_frames * PLANES_PER_FRAME * (size_t)lv.n;
+      const size_t bytes = (size_t)n_frames * lv.frame_bytes;
       hipError_t he = hipMalloc(&lv.planes, bytes);
       if (he != hipSuccess) { free_pool(e); return fail(PHOVO_E_HIP, std::string("hipMalloc(frame pool): ") + hipGetErrorString(he)); }
       he = hipMemsetAsync(lv.planes, 0, bytes, e->stream);
@@ -421,6 +488,10 @@ int phovo_engine_reserve_frames(phovo_engine *e, int n_frames, int width, int he
     if (e->cfg.blur_filter_size[l] > max_ks) max_ks = e->cfg.blur_filter_size[l];
   }
   hipError_t he = hipSuccess;        // raw-frame staging is allocated on first upload (ensure_stage)
+  {   // fp64 scratch: one staging chunk of planes for the narrow storages, one frame for plane get/set otherwise
+    const size_t frames = e->ext.plane_storage == PHOVO_STORAGE_F64 ? 1 : (size_t)STAGE_CHUNK;
+    he = hipMalloc(&e->d_scratch, sizeof(double) * frames * PLANES_PER_FRAME * (max_n ? max_n : 1));
+  }
   if (he == hipSuccess && max_ks > 0) {
     he = hipMalloc(&e->d_tmp, sizeof(double) * (max_n ? max_n : 1));
     if (he == hipSuccess) he = hipMalloc(&e->d_blur_kernel, sizeof(double) * (size_t)max_ks * PHOVO_MAX_LEVELS);
@@ -570,12 +641,19 @@ int phovo_engine_set_level_planes(phovo_engine *e, int frame, int level,
   if (st != PHOVO_OK) return st;
   PHOVO_HIP_CHECK(hipSetDevice(e->device));
   const LevelPool &lv = e->levels[level];
-  double *base = lv.planes + (size_t)frame * PLANES_PER_FRAME * (size_t)lv.n;
+  unsigned char *base = lv.planes + (size_t)frame * lv.frame_bytes;
   const double *srcs[4] = {intensity, depth, grad_x, grad_y};
   for (int p = 0; p < 4; p++) {
     if (!srcs[p]) continue;
-    PHOVO_HIP_CHECK(hipMemcpyAsync(base + (size_t)p * lv.n, srcs[p], sizeof(double) * (size_t)lv.n,
-                                   hipMemcpyHostToDevice, e->stream));
+    if (e->ext.plane_storage == PHOVO_STORAGE_F64) {
+      PHOVO_HIP_CHECK(hipMemcpyAsync(base + lv.plane_off[p], srcs[p], sizeof(double) * (size_t)lv.n,
+                                     hipMemcpyHostToDevice, e->stream));
+    } else {                                   // round to the storage type on the device, like the producers do
+      PHOVO_HIP_CHECK(hipMemcpyAsync(e->d_scratch, srcs[p], sizeof(double) * (size_t)lv.n, hipMemcpyHostToDevice, e->stream));
+      PHOVO_HIP_CHECK(pyr_store_plane(e->d_scratch, 0, 1, lv.n, base + lv.plane_off[p], lv.frame_bytes,
+                                      e->ext.plane_storage, p == PLANE_D, e->stream));
+      PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
+    }
   }
   PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
   return PHOVO_OK;
@@ -588,12 +666,18 @@ int phovo_engine_get_level_planes(const phovo_engine *e, int frame, int level,
   if (st != PHOVO_OK) return st;
   PHOVO_HIP_CHECK(hipSetDevice(e->device));
   const LevelPool &lv = e->levels[level];
-  const double *base = lv.planes + (size_t)frame * PLANES_PER_FRAME * (size_t)lv.n;
+  const unsigned char *base = lv.planes + (size_t)frame * lv.frame_bytes;
   double *dsts[4] = {intensity, depth, grad_x, grad_y};
   PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
   for (int p = 0; p < 4; p++) {
     if (!dsts[p]) continue;
-    PHOVO_HIP_CHECK(hipMemcpy(dsts[p], base + (size_t)p * lv.n, sizeof(double) * (size_t)lv.n, hipMemcpyDeviceToHost));
+    if (e->ext.plane_storage == PHOVO_STORAGE_F64) {
+      PHOVO_HIP_CHECK(hipMemcpy(dsts[p], base + lv.plane_off[p], sizeof(double) * (size_t)lv.n, hipMemcpyDeviceToHost));
+    } else {
+      PHOVO_HIP_CHECK(pyr_load_plane(base + lv.plane_off[p], lv.n, e->d_scratch, e->ext.plane_storage, p == PLANE_D, e->stream));
+      PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
+      PHOVO_HIP_CHECK(hipMemcpy(dsts[p], e->d_scratch, sizeof(double) * (size_t)lv.n, hipMemcpyDeviceToHost));
+    }
   }
   return PHOVO_OK;
 }
@@ -660,11 +744,14 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
     a.ifx = 1.f / a.fx; a.ify = 1.f / a.fy;                                          // :208-209
     a.min_depth = e->min_depth; a.max_depth = e->max_depth;
     a.planes = lv.planes;
+    a.frame_bytes = lv.frame_bytes;
+    for (int p = 0; p < PLANES_PER_FRAME; p++) a.plane_off[p] = lv.plane_off[p];
+    a.huber_delta = e->ext.huber_delta[l];
     a.src = e->d_src; a.tgt = e->d_tgt;
     a.states = e->d_states; a.reports = e->d_reports;
     a.g_owner = e->d_owner;
     PHOVO_HIP_CHECK(hipEventRecord(e->ev_start[l], e->stream));
-    PHOVO_HIP_CHECK(gn_launch_level(a, lv.plan, n_pairs, e->stream));
+    PHOVO_HIP_CHECK(gn_launch_level(a, lv.plan, e->ext.plane_storage, n_pairs, e->stream));
     PHOVO_HIP_CHECK(hipEventRecord(e->ev_stop[l], e->stream));
     e->level_launched[l] = true;
   }
@@ -817,11 +904,25 @@ int phovo_odometry_set_config(phovo_odometry *o, const phovo_config *cfg)
   return st;
 }
 
+int phovo_odometry_set_extensions(phovo_odometry *o, const phovo_extensions *ext)
+{
+  if (!o) return fail(PHOVO_E_INVALID_ARGUMENT, "set_extensions: null");
+  const int before = o->engine->ext.plane_storage;
+  const int st = phovo_engine_set_extensions(o->engine, ext);
+  if (st == PHOVO_OK && ext->plane_storage != before) o->have_source = o->have_target = o->optimized = false;
+  return st;
+}
+
 int phovo_odometry_read_configuration_file(phovo_odometry *o, const char *path)
 {
   if (!o) return fail(PHOVO_E_INVALID_ARGUMENT, "ReadConfigurationFile: null");
   phovo_config c;
-  const int st = read_config_file(path, &c);
+  int st = read_config_file(path, &c);
+  if (st != PHOVO_OK) return st;
+  phovo_extensions x;                        // optional keys; a reference yml has none -> everything stays off
+  st = read_extensions_file(path, &x);
+  if (st != PHOVO_OK) return st;
+  st = phovo_odometry_set_extensions(o, &x);
   if (st != PHOVO_OK) return st;
   return phovo_odometry_set_config(o, &c);
 }

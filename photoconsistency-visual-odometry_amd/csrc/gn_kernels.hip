@@ -28,8 +28,10 @@
 // parity with the reference's poses requires it ("read this first" item 4).
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "phovo_internal.hpp"
 
@@ -190,14 +192,31 @@ __device__ __forceinline__ void solve6_ldlt(const double (&h)[21], const double 
 // (8*k) in a VGPR while the bases sit in SGPRs, and a read past the plane returns 0 instead of needing
 // a branch (raw buffer, num_records = plane bytes).  Flat loads cost a 64-bit VGPR address per plane.
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const double *p, int n)
+template <typename T>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const unsigned char *p, int n)
 {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p), 0, n * 8, 0x00020000);
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(p), 0, n * (int)sizeof(T), 0x00020000);
 }
-__device__ __forceinline__ double plane_load(__amdgpu_buffer_rsrc_t r, int byte_off)
+// Element `idx` of a plane stored as T, widened to fp64 (all arithmetic stays fp64; narrower storage is the
+// opt-in extension of include/phovo_hip.h, PHOVO_STORAGE_*).  idx = -1 or past the plane reads 0.
+template <typename T>
+__device__ __forceinline__ double plane_load(__amdgpu_buffer_rsrc_t r, int idx);
+template <>
+__device__ __forceinline__ double plane_load<double>(__amdgpu_buffer_rsrc_t r, int idx)
 {
-  const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0);
+  const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, idx * 8, 0, 0);
   return __hiloint2double((int)v.y, (int)v.x);
+}
+template <>
+__device__ __forceinline__ double plane_load<float>(__amdgpu_buffer_rsrc_t r, int idx)
+{
+  return (double)__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, idx * 4, 0, 0));
+}
+template <>
+__device__ __forceinline__ double plane_load<__half>(__amdgpu_buffer_rsrc_t r, int idx)
+{
+  const unsigned short bits = __builtin_amdgcn_raw_buffer_load_b16(r, idx * 2, 0, 0);
+  return (double)__half2float(__ushort_as_half(bits));
 }
 
 // 1/x to within one ulp: v_rcp_f64 seeds two Newton steps.  The IEEE-exact division sequence is
@@ -216,7 +235,8 @@ __device__ __forceinline__ double fast_rcp(double x)
 // (2 workgroups of 512 threads per CU <=> 4).  SRC_LDS: source intensity plane staged in LDS.
 // OWNER_LDS: owner map in LDS (else in global memory).  MASK_REG: the per-pixel "warped in bounds"
 // flags of a lane live in one 64-bit register (needs <= 64 chunks per wave), else in an LDS ballot array.
-template <int T, int WPS, bool SRC_LDS, bool OWNER_LDS, bool MASK_REG>
+// TI / TD: storage type of the intensity+gradient planes / of the depth plane (double = reference-exact).
+template <int T, int WPS, bool SRC_LDS, bool OWNER_LDS, bool MASK_REG, typename TI, typename TD>
 __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
 {
   constexpr int NW = T / WAVE;
@@ -240,24 +260,21 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
   const int pair = blockIdx.x;
   const int n = A.n, W = A.w, H = A.h;
 
-  const size_t fstride = (size_t)PLANES_PER_FRAME * (size_t)n;
-  const double *src_frame = A.planes + (size_t)A.src[pair] * fstride;
-  const double *tgt_frame = A.planes + (size_t)A.tgt[pair] * fstride;
-  const double *__restrict__ I0 = src_frame + (size_t)PLANE_I * n;
-  const double *__restrict__ D0 = src_frame + (size_t)PLANE_D * n;
-  const double *__restrict__ I1 = tgt_frame + (size_t)PLANE_I * n;
-  const double *__restrict__ GX = tgt_frame + (size_t)PLANE_GX * n;
-  const double *__restrict__ GY = tgt_frame + (size_t)PLANE_GY * n;
+  const unsigned char *src_frame = A.planes + (size_t)A.src[pair] * A.frame_bytes;
+  const unsigned char *tgt_frame = A.planes + (size_t)A.tgt[pair] * A.frame_bytes;
   int *g_owner = OWNER_LDS ? nullptr : A.g_owner + (size_t)pair * (size_t)n;
-  const __amdgpu_buffer_rsrc_t rI0 = plane_rsrc(I0, n), rD0 = plane_rsrc(D0, n);
-  const __amdgpu_buffer_rsrc_t rI1 = plane_rsrc(I1, n), rGX = plane_rsrc(GX, n), rGY = plane_rsrc(GY, n);
+  const __amdgpu_buffer_rsrc_t rI0 = plane_rsrc<TI>(src_frame + A.plane_off[PLANE_I], n);
+  const __amdgpu_buffer_rsrc_t rD0 = plane_rsrc<TD>(src_frame + A.plane_off[PLANE_D], n);
+  const __amdgpu_buffer_rsrc_t rI1 = plane_rsrc<TI>(tgt_frame + A.plane_off[PLANE_I], n);
+  const __amdgpu_buffer_rsrc_t rGX = plane_rsrc<TI>(tgt_frame + A.plane_off[PLANE_GX], n);
+  const __amdgpu_buffer_rsrc_t rGY = plane_rsrc<TI>(tgt_frame + A.plane_off[PLANE_GY], n);
 
   // ---- level prologue -------------------------------------------------------------------
   if (OWNER_LDS) {
     for (int k = tid; k < n; k += T) s_owner[k] = -1;
   }   // the global owner map is cleared by the host before the launch and re-cleared in pass 2
   if (SRC_LDS) {
-    for (int k = tid; k < n; k += T) s_i0[k] = I0[k];
+    for (int k = tid; k < n; k += T) s_i0[k] = plane_load<TI>(rI0, k);
   }
   if (wave == 0) {
     double st[6];
@@ -276,6 +293,12 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
   const double fx = A.fx, fy = A.fy, ox = A.ox, oy = A.oy, ifx = A.ifx, ify = A.ify;
   const double min_d = A.min_depth, max_d = A.max_depth;
   const double dW = (double)W, dH = (double)H;
+  const double huber_delta = A.huber_delta;
+#ifdef PHOVO_AB_NO_HUBER          // A/B diagnostic build only (tools/): compiles the extension out
+  const bool huber_on = false;
+#else
+  const bool huber_on = huber_delta > 0.0;
+#endif
 
   // A wave walks the image in chunks of 64 consecutive pixels, NW chunks apart; (row, column) of a
   // lane's pixel is carried along instead of divided out per pixel.
@@ -306,11 +329,11 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
       int k = k0, r = r0, c = c0, j = 0;
       // software prefetch: the depth of the NEXT chunk is requested before this chunk is processed, so
       // every wave keeps a load in flight while it computes (the passes are bound by bytes in flight per CU)
-      double pz_next = plane_load(rD0, k * 8);
+      double pz_next = plane_load<TD>(rD0, k);
 #pragma unroll 2
       for (int chunk = wave; chunk < A.n_chunks; chunk += NW, j++) {
         const double pz = pz_next;                                        // :279
-        pz_next = plane_load(rD0, (k + NW * WAVE) * 8);                   // past the plane: 0
+        pz_next = plane_load<TD>(rD0, k + NW * WAVE);                     // past the plane: 0
         bool inb = false;
         {
           if (k < n && min_d < pz && pz < max_d) {                        // :280
@@ -356,7 +379,10 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
 #pragma unroll
     for (int j = 0; j < NRED; j++) acc[j] = 0.0;
 
-    {
+    // Pass 2 exists in two compiled copies, selected by a wave-uniform branch OUTSIDE the pixel loop, so that the
+    // reference path (no Huber weights) carries none of the extension's instructions.
+    auto pass2 = [&](auto huber_tag) {
+      constexpr bool HUBER = decltype(huber_tag)::value;
       int k = k0, r = r0, c = c0, j = 0;
       // software prefetch, as in pass 1: owner + four planes of the NEXT chunk are requested (and the
       // gathered source intensity right behind them) before this chunk's arithmetic starts.
@@ -373,12 +399,12 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
             __hip_atomic_store(&g_owner[kk], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
-        pz_n = plane_load(rD0, kk * 8);
-        gx_n = plane_load(rGX, kk * 8);             // gradient at the SOURCE index  :346-347
-        gy_n = plane_load(rGY, kk * 8);
-        i1_n = plane_load(rI1, kk * 8);             // :309
+        pz_n = plane_load<TD>(rD0, kk);
+        gx_n = plane_load<TI>(rGX, kk);             // gradient at the SOURCE index  :346-347
+        gy_n = plane_load<TI>(rGY, kk);
+        i1_n = plane_load<TI>(rI1, kk);             // :309
         if (SRC_LDS) { if (o_n >= 0) i0_n = s_i0[o_n]; }
-        else i0_n = plane_load(rI0, o_n * 8);       // :308 of the owning source pixel (o = -1: offset past the plane -> 0)
+        else i0_n = plane_load<TI>(rI0, o_n);       // :308 of the owning source pixel (o = -1: offset past the plane -> 0)
       };
       fetch(k);
 #pragma unroll 2
@@ -420,22 +446,32 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
           J[4] = (J[0] * cosy + J[1] * siny) * Zr + Cm * J[2];            // :333-336
           J[5] = J[0] * (py * t4 + pz * t21) + J[1] * (pz * t7 + py * t9) + Dm * J[2];                   // :339-342
 
+          double Jw[6];
+#pragma unroll
+          for (int a = 0; a < 6; a++) Jw[a] = J[a];
+          if (HUBER) {         // extension, not in the reference: IRLS weight of the Huber loss
+            const double ar = fabs(res);
+            const double wgt = ar <= huber_delta ? 1.0 : huber_delta / ar;
+#pragma unroll
+            for (int a = 0; a < 6; a++) Jw[a] = J[a] * wgt;
+          }
           int q = 0;
 #pragma unroll
           for (int a = 0; a < 6; a++) {
 #pragma unroll
             for (int b = a; b < 6; b++) {
-              acc[q] = fma(J[a], J[b], acc[q]);                                         // J^T J  :540
+              acc[q] = fma(Jw[a], J[b], acc[q]);                                        // J^T (W) J  :540
               q++;
             }
           }
 #pragma unroll
-          for (int a = 0; a < 6; a++) acc[21 + a] = fma(J[a], res, acc[21 + a]);         // J^T r  :538
+          for (int a = 0; a < 6; a++) acc[21 + a] = fma(Jw[a], res, acc[21 + a]);        // J^T (W) r  :538
         }
         k += NW * WAVE; c += step_c; r += step_r;
         if (c >= W) { c -= W; r += 1; }
       }
-    }
+    };
+    if (huber_on) pass2(std::true_type{}); else pass2(std::false_type{});
 
     PHOVO_STAMP(2)
     // ---- wave-level transposed butterfly: 32 shuffles, lane l ends with value index idx(l) ----
@@ -536,11 +572,12 @@ size_t lds_fixed_bytes(int threads)
 //   QUAD   256 threads, 4 workgroups/CU, owner map in LDS, source intensity gathered from L2
 enum Variant { V_TINY = 0, V_MID, V_WIDE, V_HUGE, V_QUAD };
 
-#define PHOVO_KERNEL_TINY  gn_level_kernel<256, 4, true, true, true>
-#define PHOVO_KERNEL_MID   gn_level_kernel<512, 4, false, true, true>
-#define PHOVO_KERNEL_WIDE  gn_level_kernel<1024, 4, false, true, true>
-#define PHOVO_KERNEL_HUGE  gn_level_kernel<1024, 4, false, false, false>
-#define PHOVO_KERNEL_QUAD  gn_level_kernel<256, 4, false, true, true>
+// ... times the three plane storages (fp64 = reference-exact; fp32; fp16 images + fp32 depth).
+#define PHOVO_KERNEL_TINY(TI, TD)  gn_level_kernel<256, 4, true, true, true, TI, TD>
+#define PHOVO_KERNEL_MID(TI, TD)   gn_level_kernel<512, 4, false, true, true, TI, TD>
+#define PHOVO_KERNEL_WIDE(TI, TD)  gn_level_kernel<1024, 4, false, true, true, TI, TD>
+#define PHOVO_KERNEL_HUGE(TI, TD)  gn_level_kernel<1024, 4, false, false, false, TI, TD>
+#define PHOVO_KERNEL_QUAD(TI, TD)  gn_level_kernel<256, 4, false, true, true, TI, TD>
 
 }  // namespace
 
@@ -584,12 +621,13 @@ bool gn_plan_level(int n, GNLaunchPlan *plan)
   return true;
 }
 
-hipError_t gn_prepare_kernels()
+template <typename TI, typename TD>
+hipError_t prepare_storage()
 {
   hipError_t e;
-#define PHOVO_PREP(K)                                                                             \
-  e = hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                          (int)LDS_LIMIT);                                                        \
+#define PHOVO_PREP(K)                                                                                      \
+  e = hipFuncSetAttribute(reinterpret_cast<const void *>(&K(TI, TD)), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                          (int)LDS_LIMIT);                                                                 \
   if (e != hipSuccess) return e;
   PHOVO_PREP(PHOVO_KERNEL_TINY)
   PHOVO_PREP(PHOVO_KERNEL_MID)
@@ -600,21 +638,40 @@ hipError_t gn_prepare_kernels()
   return hipSuccess;
 }
 
-hipError_t gn_launch_level(const GNLevelArgs &a, const GNLaunchPlan &plan, int n_pairs,
-                           hipStream_t stream)
+template <typename TI, typename TD>
+hipError_t launch_storage(const GNLevelArgs &a, const GNLaunchPlan &plan, int n_pairs, hipStream_t stream)
 {
-  if (n_pairs <= 0) return hipSuccess;
   const size_t lds = (size_t)plan.lds_bytes;
   const dim3 grid((unsigned)n_pairs), block((unsigned)plan.threads);
   switch (plan.variant) {
-    case V_TINY:  hipLaunchKernelGGL(PHOVO_KERNEL_TINY, grid, block, lds, stream, a); break;
-    case V_MID:   hipLaunchKernelGGL(PHOVO_KERNEL_MID, grid, block, lds, stream, a); break;
-    case V_WIDE:  hipLaunchKernelGGL(PHOVO_KERNEL_WIDE, grid, block, lds, stream, a); break;
-    case V_HUGE:  hipLaunchKernelGGL(PHOVO_KERNEL_HUGE, grid, block, lds, stream, a); break;
-    case V_QUAD:  hipLaunchKernelGGL(PHOVO_KERNEL_QUAD, grid, block, lds, stream, a); break;
+    case V_TINY:  hipLaunchKernelGGL(PHOVO_KERNEL_TINY(TI, TD), grid, block, lds, stream, a); break;
+    case V_MID:   hipLaunchKernelGGL(PHOVO_KERNEL_MID(TI, TD), grid, block, lds, stream, a); break;
+    case V_WIDE:  hipLaunchKernelGGL(PHOVO_KERNEL_WIDE(TI, TD), grid, block, lds, stream, a); break;
+    case V_HUGE:  hipLaunchKernelGGL(PHOVO_KERNEL_HUGE(TI, TD), grid, block, lds, stream, a); break;
+    case V_QUAD:  hipLaunchKernelGGL(PHOVO_KERNEL_QUAD(TI, TD), grid, block, lds, stream, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
+}
+
+hipError_t gn_prepare_kernels()
+{
+  hipError_t e;
+  if ((e = prepare_storage<double, double>()) != hipSuccess) return e;
+  if ((e = prepare_storage<float, float>()) != hipSuccess) return e;
+  return prepare_storage<__half, float>();
+}
+
+hipError_t gn_launch_level(const GNLevelArgs &a, const GNLaunchPlan &plan, int storage, int n_pairs,
+                           hipStream_t stream)
+{
+  if (n_pairs <= 0) return hipSuccess;
+  switch (storage) {
+    case PHOVO_STORAGE_F64: return launch_storage<double, double>(a, plan, n_pairs, stream);
+    case PHOVO_STORAGE_F32: return launch_storage<float, float>(a, plan, n_pairs, stream);
+    case PHOVO_STORAGE_F16: return launch_storage<__half, float>(a, plan, n_pairs, stream);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 }  // namespace phovo_hip

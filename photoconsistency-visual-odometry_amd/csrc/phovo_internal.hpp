@@ -24,7 +24,10 @@ struct GNLevelArgs {
   double min_grad_norm;     // min_gradient_norm[level]
   double fx, fy, ox, oy, ifx, ify;   // level-scaled intrinsics (...Analytic.h:203-209)
   double min_depth, max_depth;
-  const double *planes;     // pool of this level: [frame][PLANES_PER_FRAME][n]
+  double huber_delta;       // > 0: Huber IRLS weights (extension, not in the reference); <= 0: off
+  const unsigned char *planes;   // pool of this level: frame f at planes + f*frame_bytes,
+  size_t frame_bytes;            //   plane p of a frame at + plane_off[p], n elements of the storage type
+  size_t plane_off[PLANES_PER_FRAME];
   const int *src;           // [pairs] source frame of each pair
   const int *tgt;           // [pairs] target frame of each pair
   double *states;           // [pairs][6] in: initial / previous level, out: updated
@@ -43,7 +46,7 @@ struct GNLaunchPlan {
 // Chooses the launch geometry for a level of n pixels.  Returns false if the level cannot be
 // handled (inbound-mask does not fit LDS).
 bool gn_plan_level(int n, GNLaunchPlan *plan);
-hipError_t gn_launch_level(const GNLevelArgs &args, const GNLaunchPlan &plan, int n_pairs,
+hipError_t gn_launch_level(const GNLevelArgs &args, const GNLaunchPlan &plan, int storage, int n_pairs,
                            hipStream_t stream);
 hipError_t gn_prepare_kernels();   // raises the dynamic-LDS limit of every instantiation
 
@@ -58,6 +61,12 @@ hipError_t pyr_depth_level_u16(const uint16_t *depth, size_t src_frame_stride, d
                                hipStream_t stream);
 hipError_t pyr_scharr(const double *base, size_t frame_stride, size_t img_off, size_t gx_off, size_t gy_off,
                       int frames, int w, int h, double scale, hipStream_t stream);
+// fp64 <-> storage-type plane conversion (storage = PHOVO_STORAGE_*, is_depth selects the depth element type).
+size_t storage_elem_size(int storage, bool is_depth);
+hipError_t pyr_store_plane(const double *src, size_t src_frame_stride, int frames, int n, unsigned char *dst,
+                           size_t dst_frame_bytes, int storage, bool is_depth, hipStream_t stream);
+hipError_t pyr_load_plane(const unsigned char *src, int n, double *dst, int storage, bool is_depth,
+                          hipStream_t stream);
 hipError_t pyr_gaussian_blur(double *img, double *tmp, int w, int h, int ksize,
                              const double *d_kernel, hipStream_t stream);
 hipError_t fill_i32(int *dst, size_t n, int value, hipStream_t stream);
@@ -68,5 +77,6 @@ int fail(int status, const std::string &msg);
 
 // OpenCV-FileStorage-dialect reader (yml_config.cpp)
 int read_config_file(const char *path, phovo_config *cfg);
+int read_extensions_file(const char *path, phovo_extensions *ext);
 
 }  // namespace phovo_hip

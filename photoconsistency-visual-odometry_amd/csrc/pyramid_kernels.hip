@@ -10,6 +10,7 @@
 // (apps/PhotoconsistencyFrameAlignment/PhotoconsistencyFrameAlignment.cpp:94-101).
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 
 #include "phovo_internal.hpp"
 
@@ -154,6 +155,32 @@ __global__ __launch_bounds__(256) void k_fill_i32(int *dst, size_t n, int value)
   for (; i < n; i += stride) dst[i] = value;
 }
 
+// Rounding to the storage type: fp64 -> fp32 is one IEEE round-to-nearest-even; fp16 goes through fp32.
+__device__ __forceinline__ void put(double *p, double v) { *p = v; }
+__device__ __forceinline__ void put(float *p, double v) { *p = (float)v; }
+__device__ __forceinline__ void put(__half *p, double v) { *p = __float2half_rn((float)v); }
+__device__ __forceinline__ double get(const double *p) { return *p; }
+__device__ __forceinline__ double get(const float *p) { return (double)*p; }
+__device__ __forceinline__ double get(const __half *p) { return (double)__half2float(*p); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_store_plane(const double *src_base, size_t src_frame_stride, int n,
+                                                     unsigned char *dst_base, size_t dst_frame_bytes)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double *src = src_base + (size_t)blockIdx.z * src_frame_stride;
+  T *dst = reinterpret_cast<T *>(dst_base + (size_t)blockIdx.z * dst_frame_bytes);
+  put(dst + i, src[i]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_load_plane(const unsigned char *src, int n, double *dst)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = get(reinterpret_cast<const T *>(src) + i);
+}
+
 inline dim3 grid3d(int w, int h, int frames)
 {
   return dim3((unsigned)((w + 255) / 256), (unsigned)h, (unsigned)frames);
@@ -190,6 +217,34 @@ hipError_t pyr_scharr(const double *base, size_t frame_stride, size_t img_off, s
 {
   hipLaunchKernelGGL(k_scharr, grid3d(w, h, frames), dim3(256), 0, stream, base, frame_stride, img_off, gx_off,
                      gy_off, w, h, scale);
+  return hipGetLastError();
+}
+
+size_t storage_elem_size(int storage, bool is_depth)
+{
+  if (storage == PHOVO_STORAGE_F32) return 4;
+  if (storage == PHOVO_STORAGE_F16) return is_depth ? 4 : 2;
+  return 8;
+}
+
+hipError_t pyr_store_plane(const double *src, size_t src_frame_stride, int frames, int n, unsigned char *dst,
+                           size_t dst_frame_bytes, int storage, bool is_depth, hipStream_t stream)
+{
+  const dim3 grid((unsigned)((n + 255) / 256), 1, (unsigned)frames);
+  const size_t es = storage_elem_size(storage, is_depth);
+  if (es == 8) hipLaunchKernelGGL(k_store_plane<double>, grid, dim3(256), 0, stream, src, src_frame_stride, n, dst, dst_frame_bytes);
+  else if (es == 4) hipLaunchKernelGGL(k_store_plane<float>, grid, dim3(256), 0, stream, src, src_frame_stride, n, dst, dst_frame_bytes);
+  else hipLaunchKernelGGL(k_store_plane<__half>, grid, dim3(256), 0, stream, src, src_frame_stride, n, dst, dst_frame_bytes);
+  return hipGetLastError();
+}
+
+hipError_t pyr_load_plane(const unsigned char *src, int n, double *dst, int storage, bool is_depth, hipStream_t stream)
+{
+  const dim3 grid((unsigned)((n + 255) / 256));
+  const size_t es = storage_elem_size(storage, is_depth);
+  if (es == 8) hipLaunchKernelGGL(k_load_plane<double>, grid, dim3(256), 0, stream, src, n, dst);
+  else if (es == 4) hipLaunchKernelGGL(k_load_plane<float>, grid, dim3(256), 0, stream, src, n, dst);
+  else hipLaunchKernelGGL(k_load_plane<__half>, grid, dim3(256), 0, stream, src, n, dst);
   return hipGetLastError();
 }
 

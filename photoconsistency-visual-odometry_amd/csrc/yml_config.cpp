@@ -93,7 +93,7 @@ int read_config_file(const char *path, phovo_config *cfg)
     }
     const std::string t = trim(line);
     if (t.empty() || t[0] == '#' || t[0] == '%' || t == "---" || t == "...") continue;
-    // the key ends at the LAST ':' that is followed by whitespace or end of line and precedes the value
+    // the key ends at the FIRST ':' that is followed by whitespace or end of line
     size_t colon = std::string::npos;
     for (size_t i = 0; i < t.size(); i++) {
       if (t[i] == ':' && (i + 1 == t.size() || std::isspace((unsigned char)t[i + 1]))) { colon = i; break; }
@@ -153,6 +153,41 @@ int read_config_file(const char *path, phovo_config *cfg)
   if (!get("visualizeIterations", &v) || v.size() != 1) return PHOVO_E_CONFIG;                 // :606
   c.visualize_iterations = v[0] != 0.0 ? 1 : 0;
   *cfg = c;
+  return PHOVO_OK;
+}
+
+
+// Optional extension keys (not in the reference).  Same line format; everything else in the file is ignored.
+int read_extensions_file(const char *path, phovo_extensions *ext)
+{
+  if (!path || !ext) return fail(PHOVO_E_INVALID_ARGUMENT, "read_extensions_file: null argument");
+  std::ifstream in(path);
+  if (!in.is_open()) return fail(PHOVO_E_IO, std::string("cannot open configuration file ") + path);
+  phovo_extensions e;
+  phovo_extensions_default(&e);
+  std::string line;
+  while (std::getline(in, line)) {
+    if (!line.empty() && line.back() == '\r') line.pop_back();
+    const std::string t = trim(line);
+    if (t.empty() || t[0] == '#' || t[0] == '%') continue;
+    size_t colon = std::string::npos;
+    for (size_t i = 0; i < t.size(); i++)
+      if (t[i] == ':' && (i + 1 == t.size() || std::isspace((unsigned char)t[i + 1]))) { colon = i; break; }
+    if (colon == std::string::npos) continue;
+    const std::string key = trim(t.substr(0, colon));
+    std::vector<double> v;
+    if (key == "huber_delta (at each level)") {
+      if (!parse_values(t.substr(colon + 1), &v)) return fail(PHOVO_E_CONFIG, "configuration key malformed: 'huber_delta (at each level)'");
+      for (int i = 0; i < PHOVO_MAX_LEVELS && i < (int)v.size(); i++) e.huber_delta[i] = v[i];
+    } else if (key == "plane_storage_bits") {
+      if (!parse_values(t.substr(colon + 1), &v) || v.size() != 1) return fail(PHOVO_E_CONFIG, "configuration key malformed: 'plane_storage_bits'");
+      if (v[0] == 64) e.plane_storage = PHOVO_STORAGE_F64;
+      else if (v[0] == 32) e.plane_storage = PHOVO_STORAGE_F32;
+      else if (v[0] == 16) e.plane_storage = PHOVO_STORAGE_F16;
+      else return fail(PHOVO_E_CONFIG, "plane_storage_bits must be 64, 32 or 16");
+    }
+  }
+  *ext = e;
   return PHOVO_OK;
 }
 

@@ -35,6 +35,17 @@ class Config(C.Structure):
     ]
 
 
+STORAGE_F64, STORAGE_F32, STORAGE_F16 = 0, 1, 2
+
+
+class Extensions(C.Structure):
+    _fields_ = [
+        ("plane_storage", C.c_int),
+        ("reserved", C.c_int),
+        ("huber_delta", C.c_double * MAX_LEVELS),
+    ]
+
+
 class PairReport(C.Structure):
     _fields_ = [
         ("iterations", C.c_int * MAX_LEVELS),
@@ -55,11 +66,14 @@ SYMBOLS = {
     "phovo_device_count": (C.c_int, []),
     "phovo_config_default": (C.c_int, [C.POINTER(Config)]),
     "phovo_config_read_file": (C.c_int, [C.c_char_p, C.POINTER(Config)]),
+    "phovo_extensions_default": (C.c_int, [C.POINTER(Extensions)]),
+    "phovo_extensions_read_file": (C.c_int, [C.c_char_p, C.POINTER(Extensions)]),
     "phovo_eigen_pose": (C.c_int, [_dp, _dp]),
     "phovo_odometry_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "phovo_odometry_destroy": (C.c_int, [_vp]),
     "phovo_odometry_read_configuration_file": (C.c_int, [_vp, C.c_char_p]),
     "phovo_odometry_set_config": (C.c_int, [_vp, C.POINTER(Config)]),
+    "phovo_odometry_set_extensions": (C.c_int, [_vp, C.POINTER(Extensions)]),
     "phovo_odometry_set_min_depth": (C.c_int, [_vp, C.c_double]),
     "phovo_odometry_set_max_depth": (C.c_int, [_vp, C.c_double]),
     "phovo_odometry_set_intrinsic_matrix": (C.c_int, [_vp, _dp]),
@@ -75,6 +89,8 @@ SYMBOLS = {
     "phovo_engine_destroy": (C.c_int, [_vp]),
     "phovo_engine_set_config": (C.c_int, [_vp, C.POINTER(Config)]),
     "phovo_engine_get_config": (C.c_int, [_vp, C.POINTER(Config)]),
+    "phovo_engine_set_extensions": (C.c_int, [_vp, C.POINTER(Extensions)]),
+    "phovo_engine_get_extensions": (C.c_int, [_vp, C.POINTER(Extensions)]),
     "phovo_engine_set_intrinsic_matrix": (C.c_int, [_vp, _dp]),
     "phovo_engine_set_depth_range": (C.c_int, [_vp, C.c_double, C.c_double]),
     "phovo_engine_set_build_all_levels": (C.c_int, [_vp, C.c_int]),
@@ -155,6 +171,22 @@ def make_config(num_levels=None, blur=None, grad_scale=None, lam=None, max_iter=
                 arr[i] = v
     cfg.visualize_iterations = int(visualize)
     return cfg
+
+
+def make_extensions(plane_storage=STORAGE_F64, huber_delta=None):
+    ext = Extensions()
+    check(lib().phovo_extensions_default(C.byref(ext)), "phovo_extensions_default")
+    ext.plane_storage = int(plane_storage)
+    if huber_delta is not None:
+        for i, v in enumerate(list(huber_delta)[:MAX_LEVELS]):
+            ext.huber_delta[i] = float(v)
+    return ext
+
+
+def read_extensions_file(path):
+    ext = Extensions()
+    check(lib().phovo_extensions_read_file(os.fsencode(path), C.byref(ext)), "phovo_extensions_read_file")
+    return ext
 
 
 def read_config_file(path):

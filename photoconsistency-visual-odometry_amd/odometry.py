@@ -61,6 +61,10 @@ class CPhotoconsistencyOdometryAnalytic:
     def SetConfiguration(self, cfg):
         check(self._lib.phovo_odometry_set_config(self._h, C.byref(cfg)), "SetConfiguration")
 
+    def SetExtensions(self, ext):
+        """Not in the reference: plane storage / Huber weights (native.make_extensions)."""
+        check(self._lib.phovo_odometry_set_extensions(self._h, C.byref(ext)), "SetExtensions")
+
     def SetMinDepth(self, minD):
         check(self._lib.phovo_odometry_set_min_depth(self._h, float(minD)), "SetMinDepth")
 
@@ -152,7 +156,16 @@ class AlignmentEngine:
         check(self._lib.phovo_engine_set_config(self._h, C.byref(cfg)), "phovo_engine_set_config")
 
     def read_configuration_file(self, path):
+        self.set_extensions(native.read_extensions_file(path))
         self.set_config(native.read_config_file(path))
+
+    def set_extensions(self, ext):
+        check(self._lib.phovo_engine_set_extensions(self._h, C.byref(ext)), "phovo_engine_set_extensions")
+
+    def get_extensions(self):
+        ext = native.Extensions()
+        check(self._lib.phovo_engine_get_extensions(self._h, C.byref(ext)), "phovo_engine_get_extensions")
+        return ext
 
     def get_config(self):
         cfg = native.Config()

@@ -19,12 +19,21 @@ extern "C" int phovo_config_default(phovo_config *cfg)
   return 0;
 }
 
+extern "C" int phovo_extensions_default(phovo_extensions *ext)
+{
+  std::memset(ext, 0, sizeof(*ext));
+  return 0;
+}
+
 int main(int argc, char **argv)
 {
   int bad = 0;
   for (int i = 1; i < argc; i++) {
     phovo_config c;
-    const int st = phovo_hip::read_config_file(argv[i], &c);
+    int st = phovo_hip::read_config_file(argv[i], &c);
+    phovo_extensions x;
+    const int st2 = phovo_hip::read_extensions_file(argv[i], &x);
+    if (st == 0) st = st2;
     std::printf("%s -> %d %s\n", argv[i], st, st ? phovo_hip::g_err.c_str() : "");
     if (st != 0) bad++;
   }

@@ -1,0 +1,146 @@
+"""GPU tests of the extensions that are NOT in the reference (BASELINE.json configs[4]): narrow plane storage
+and Huber IRLS weights.  Parity is against the oracle extended identically (never against the reference):
+the oracle is fed the planes exactly as the device stored them (read back as fp64), so the only differences are
+the usual fp64 ones -- same 1e-9 bar as the reference-exact path."""
+import os
+
+import numpy as np
+import pytest
+
+import phovo_amd  # noqa: F401
+from phovo_amd import native, odometry, se3, synthetic
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG_DIR = os.path.join(ROOT, "config_files")
+POSE_TOL = 1e-9
+
+
+def _cfg_pair(yml, fixed_cap=None):
+    n = native.read_config_file(os.path.join(CFG_DIR, yml))
+    nl = n.num_levels
+    mi = list(n.max_num_iterations[:nl])
+    mg = list(n.min_gradient_norm[:nl])
+    if fixed_cap is not None:
+        mi = [min(m, fixed_cap) for m in mi]
+        mg = [0.0] * nl
+    return (native.make_config(num_levels=nl, max_iter=mi, min_grad=mg),
+            oracle.make_config(num_levels=nl, max_iter=mi, min_grad=mg), nl, mi)
+
+
+def _stored_planes(eng, src, tgt, nl, mi, w, h):
+    """Oracle inputs = exactly what the device holds (rounded to the storage type), levels it does not hold: zeros."""
+    i0p, d0p, i1p, gxp, gyp = [], [], [], [], []
+    for l in range(nl):
+        if mi[l] > 0:
+            i0, d0, _, _ = eng.get_level_planes(src, l)
+            i1, _, gx, gy = eng.get_level_planes(tgt, l)
+        else:
+            lw, lh = oracle.level_size(w, h, l)
+            i0 = d0 = i1 = gx = gy = np.zeros((lh, lw))
+        i0p.append(i0); d0p.append(d0); i1p.append(i1); gxp.append(gx); gyp.append(gy)
+    return i0p, d0p, i1p, gxp, gyp
+
+
+@pytest.mark.parametrize("storage", [native.STORAGE_F32, native.STORAGE_F16])
+def test_narrow_storage_rounds_once_and_matches_oracle(storage):
+    p = synthetic.make_pair(21, 640, 480, holes=0.02)
+    ncfg, ocfg, nl, mi = _cfg_pair("config_4_level_optimization_analytic.yml")
+    ref_i0, ref_d0 = oracle.build_source_pyramids(p["gray0"], p["depth0"], ocfg)
+    ref_i1, ref_gx, ref_gy = oracle.build_target_pyramids(p["gray1"], ocfg)
+    with odometry.AlignmentEngine() as eng:
+        eng.set_config(ncfg)
+        eng.set_extensions(native.make_extensions(plane_storage=storage))
+        eng.set_intrinsic_matrix(p["K"])
+        eng.reserve_frames(2, 640, 480)
+        eng.upload_frame(0, p["gray0"], p["depth0"])
+        eng.upload_frame(1, p["gray1"], p["depth1"])
+        i0p, d0p, i1p, gxp, gyp = _stored_planes(eng, 0, 1, nl, mi, 640, 480)
+        # stored planes = fp64 pyramids rounded ONCE to the storage type (fp16 goes through fp32)
+        img_t = (lambda a: a.astype(np.float32).astype(np.float64)) if storage == native.STORAGE_F32 else \
+                (lambda a: a.astype(np.float32).astype(np.float16).astype(np.float64))
+        dep_t = lambda a: a.astype(np.float32).astype(np.float64)
+        for l in range(nl):
+            if mi[l] == 0:
+                continue
+            np.testing.assert_array_equal(i0p[l], img_t(ref_i0[l]))
+            np.testing.assert_array_equal(d0p[l], dep_t(ref_d0[l]))
+            np.testing.assert_array_equal(gxp[l], img_t(ref_gx[l]))
+            np.testing.assert_array_equal(gyp[l], img_t(ref_gy[l]))
+        es, eits = oracle.optimize(ocfg, p["K"], i0p, d0p, i1p, gxp, gyp)
+        s, reps = eng.align_pairs([0], [1], want_reports=True)
+        # set_level_planes rounds the same way: feeding the unrounded oracle planes gives the same stored bits
+        eng.set_level_planes(0, 3, intensity=ref_i0[3], depth=ref_d0[3])
+        a, b, _, _ = eng.get_level_planes(0, 3)
+        np.testing.assert_array_equal(a, i0p[3])
+        np.testing.assert_array_equal(b, d0p[3])
+    assert list(reps[0].iterations[:nl]) == eits
+    assert se3.state_distance(s[0], es) < POSE_TOL
+    # and the narrow storage moved the answer only slightly away from the fp64 one
+    s64, _ = oracle.optimize(ocfg, p["K"], ref_i0, ref_d0, ref_i1, ref_gx, ref_gy)
+    assert se3.state_distance(s[0], s64) < (1e-4 if storage == native.STORAGE_F32 else 5e-2)
+
+
+def test_huber_weights_match_extended_oracle():
+    p = synthetic.make_pair(22, 640, 480, holes=0.02)
+    g1 = p["gray1"].copy()
+    g1[100:180, 200:330] = 255                                  # an occluder-like outlier block
+    ncfg, ocfg, nl, mi = _cfg_pair("config_4_level_optimization_analytic.yml", fixed_cap=8)
+    delta = [0.0, 0.0, 0.04, 0.06]
+    i0p, d0p = oracle.build_source_pyramids(p["gray0"], p["depth0"], ocfg)
+    i1p, gxp, gyp = oracle.build_target_pyramids(g1, ocfg)
+    es, eits, etr = oracle.optimize(ocfg, p["K"], i0p, d0p, i1p, gxp, gyp, want_trace=True, huber_delta=delta)
+    e0, _ = oracle.optimize(ocfg, p["K"], i0p, d0p, i1p, gxp, gyp)
+    with odometry.AlignmentEngine() as eng:
+        eng.set_config(ncfg)
+        eng.set_intrinsic_matrix(p["K"])
+        eng.reserve_frames(2, 640, 480)
+        eng.upload_frame(0, p["gray0"], p["depth0"])
+        eng.upload_frame(1, g1, p["depth1"])
+        plain = eng.align_pairs([0], [1])
+        eng.set_extensions(native.make_extensions(huber_delta=delta))     # same storage: the pool survives
+        s, reps = eng.align_pairs([0], [1], want_reports=True)
+        eng.set_extensions(native.make_extensions(huber_delta=[1e9] * nl))
+        huge = eng.align_pairs([0], [1])
+    assert list(reps[0].iterations[:nl]) == eits
+    assert se3.state_distance(s[0], es) < POSE_TOL
+    g_last = np.linalg.norm(etr[-1]["gradient"])
+    assert abs(reps[0].gradient_norm - g_last) <= 1e-9 * max(1.0, g_last)
+    assert se3.state_distance(plain[0], e0) < POSE_TOL
+    assert se3.state_distance(s[0], plain[0]) > 1e-5             # the weights changed the estimate
+    assert se3.state_distance(huge[0], plain[0]) < 1e-12         # delta -> inf is the least-squares path
+
+
+def test_config5_shape_huber_fp16_through_yml_and_class_surface(tmp_path):
+    """BASELINE.json configs[4]: 1280x960, config_6_level_optimization_analytic.yml + Huber + fp16 pyramids,
+    switched on by the two optional yml keys and driven through the class-shaped surface."""
+    base = open(os.path.join(CFG_DIR, "config_6_level_optimization_analytic.yml")).read()
+    yml = tmp_path / "config_6_level_huber_fp16.yml"
+    delta = [0.0, 0.0, 0.05, 0.05, 0.08, 0.1]
+    yml.write_text(base + "huber_delta (at each level): " + str(delta) + "\nplane_storage_bits: 16\n")
+    p = synthetic.make_pair(23, 1280, 960, holes=0.02)
+    n = native.read_config_file(str(yml))
+    nl = n.num_levels
+    mi = list(n.max_num_iterations[:nl])
+    ocfg = oracle.make_config(num_levels=nl, max_iter=mi, min_grad=list(n.min_gradient_norm[:nl]))
+    with odometry.AlignmentEngine() as eng:                      # the stored (fp16 / fp32) planes for the oracle
+        eng.read_configuration_file(str(yml))
+        assert eng.get_extensions().plane_storage == native.STORAGE_F16
+        eng.reserve_frames(2, 1280, 960)
+        eng.upload_frame(0, p["gray0"], p["depth0"])
+        eng.upload_frame(1, p["gray1"], p["depth1"])
+        planes = _stored_planes(eng, 0, 1, nl, mi, 1280, 960)
+    es, eits = oracle.optimize(ocfg, p["K"], *planes, huber_delta=delta)
+    with odometry.CPhotoconsistencyOdometryAnalytic() as po:
+        po.ReadConfigurationFile(str(yml))
+        po.SetIntrinsicMatrix(p["K"])
+        po.SetSourceFrame(p["gray0"], p["depth0"])
+        po.SetTargetFrame(p["gray1"], p["depth1"])
+        po.SetInitialStateVector(np.zeros(6))
+        po.Optimize()
+        s = po.GetOptimalStateVector()
+        rep = po.GetReport()
+    assert list(rep.iterations[:nl]) == eits
+    assert se3.state_distance(s, es) < POSE_TOL
