@@ -47,6 +47,10 @@ def parse():
                     help="threads of the all-cores CPU baseline (a one-GPU box's CPU share); 1 = skip it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-termination", action="store_true")
+    # extensions that are NOT in the reference; the default run (driver's BENCH/SCALE) never sets them
+    ap.add_argument("--storage", choices=["f64", "f32", "f16"], default="f64",
+                    help="plane storage (f64 = reference-exact; arithmetic is fp64 in every mode)")
+    ap.add_argument("--huber", type=float, default=0.0, help="Huber delta on every level (0 = off)")
     return ap.parse_args()
 
 
@@ -108,6 +112,11 @@ def main():
         cfg_fixed.min_gradient_norm[l] = 0.0
 
     eng = odometry.AlignmentEngine(local_rank)
+    storage_code = {"f64": native.STORAGE_F64, "f32": native.STORAGE_F32, "f16": native.STORAGE_F16}[args.storage]
+    # bytes per pixel of the five planes a pixel-iteration reads (I0, D0, I1, GX1, GY1) in this storage
+    plane_bytes = {"f64": 40.0, "f32": 20.0, "f16": 12.0}[args.storage]
+    if args.storage != "f64" or args.huber > 0:
+        eng.set_extensions(native.make_extensions(plane_storage=storage_code, huber_delta=[args.huber] * nl))
     eng.set_config(cfg_fixed)
     eng.set_intrinsic_matrix(seq["K"])
     n_frames = reps * (distinct + 1)
@@ -154,7 +163,7 @@ def main():
         if max_iter[l] <= 0:
             continue
         it_sum = float(iters[:, l].sum())
-        bytes_launch = 5.0 * 8.0 * level_sizes[l] * it_sum
+        bytes_launch = plane_bytes * level_sizes[l] * it_sum
         avg_ms = per_level_ms[l] / args.steps
         levels_out.append(dict(level=l, pixels=level_sizes[l], avg_launch_ms=avg_ms,
                                iterations_per_pair=it_sum / n_local,
@@ -279,7 +288,11 @@ def main():
             "iterations_per_pair": [float(x) for x in iters.mean(axis=0)],
             "nonfinite_pairs": nonfinite,
             "algorithmic_MB_per_alignment": algorithmic_bytes(
-                level_sizes, [m if max_iter[l] > 0 else 0.0 for l, m in enumerate(iters.mean(axis=0))]) / 1e6,
+                level_sizes, [m if max_iter[l] > 0 else 0.0 for l, m in enumerate(iters.mean(axis=0))]) / 1e6
+            * plane_bytes / 40.0,
+            "extensions": None if (args.storage == "f64" and args.huber <= 0) else
+            {"plane_storage": args.storage, "huber_delta": args.huber,
+             "note": "not in the reference; arithmetic stays fp64, planes are rounded once when stored"},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "cpu_baseline_all_cores": cpu_all,

@@ -116,6 +116,10 @@ class CPhotoconsistencyOdometryAnalytic : public CPhotoconsistencyOdometry<TPixe
     Check(phovo_odometry_read_configuration_file(m_Handle, fileName.c_str()), "ReadConfigurationFile");
   }
 
+  // Not in the reference: narrow plane storage / Huber IRLS weights (phovo_extensions in phovo_hip.h).
+  // ReadConfigurationFile() also picks them up from the two optional yml keys.
+  void SetExtensions(const phovo_extensions &ext) { Check(phovo_odometry_set_extensions(m_Handle, &ext), "SetExtensions"); }
+
   // Not in the reference: what Optimize() did (iterations per level, last gradient norm, flags) and
   // its device time.
   phovo_pair_report GetReport() const
