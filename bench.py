@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--storage", choices=["f64", "f32", "f16"], default="f64",
                     help="plane storage (f64 = reference-exact; arithmetic is fp64 in every mode)")
     ap.add_argument("--huber", type=float, default=0.0, help="Huber delta on every level (0 = off)")
+    ap.add_argument("--bilinear", action="store_true", help="bilinear forward-additive sampling + corrected Jacobian")
     return ap.parse_args()
 
 
@@ -115,8 +116,11 @@ def main():
     storage_code = {"f64": native.STORAGE_F64, "f32": native.STORAGE_F32, "f16": native.STORAGE_F16}[args.storage]
     # bytes per pixel of the five planes a pixel-iteration reads (I0, D0, I1, GX1, GY1) in this storage
     plane_bytes = {"f64": 40.0, "f32": 20.0, "f16": 12.0}[args.storage]
-    if args.storage != "f64" or args.huber > 0:
-        eng.set_extensions(native.make_extensions(plane_storage=storage_code, huber_delta=[args.huber] * nl))
+    if args.storage != "f64" or args.huber > 0 or args.bilinear:
+        eng.set_extensions(native.make_extensions(
+            plane_storage=storage_code, huber_delta=[args.huber] * nl,
+            sampling=native.SAMPLING_BILINEAR if args.bilinear else native.SAMPLING_NEAREST_SCATTER,
+            jacobian_corrected=args.bilinear))
     eng.set_config(cfg_fixed)
     eng.set_intrinsic_matrix(seq["K"])
     n_frames = reps * (distinct + 1)
@@ -290,8 +294,8 @@ def main():
             "algorithmic_MB_per_alignment": algorithmic_bytes(
                 level_sizes, [m if max_iter[l] > 0 else 0.0 for l, m in enumerate(iters.mean(axis=0))]) / 1e6
             * plane_bytes / 40.0,
-            "extensions": None if (args.storage == "f64" and args.huber <= 0) else
-            {"plane_storage": args.storage, "huber_delta": args.huber,
+            "extensions": None if (args.storage == "f64" and args.huber <= 0 and not args.bilinear) else
+            {"plane_storage": args.storage, "huber_delta": args.huber, "bilinear_corrected": args.bilinear,
              "note": "not in the reference; arithmetic stays fp64, planes are rounded once when stored"},
             "roofline": roofline,
             "cpu_baseline": cpu,

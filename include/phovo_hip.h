@@ -82,8 +82,20 @@ typedef struct phovo_pair_report {
 #define PHOVO_STORAGE_F64 0
 #define PHOVO_STORAGE_F32 1
 #define PHOVO_STORAGE_F16 2
+/* sampling: how the target frame is looked up.
+ *   PHOVO_SAMPLING_NEAREST_SCATTER  the reference's analytic path: C round() of the warped position, residual
+ *                                   scattered to the target index, Jacobian row at the source index (...Analytic.h:297-358)
+ *   PHOVO_SAMPLING_BILINEAR         forward-additive alignment with bilinear samples of intensity and gradients at the
+ *                                   real-valued warped position (in bounds iff the nearest pixel is, taps clamped to
+ *                                   the edge); residual and Jacobian row both belong to the source pixel: no scatter.
+ * jacobian_corrected (bilinear sampling only): 1 = the true warp Jacobian, i.e. without the reference's
+ * `temp11 = cos(pitch)*cos(yaw)+x` transcription slip (...Analytic.h:253); 0 = the reference's Jacobian. */
+#define PHOVO_SAMPLING_NEAREST_SCATTER 0
+#define PHOVO_SAMPLING_BILINEAR 1
 typedef struct phovo_extensions {
-  int    plane_storage;                     /* PHOVO_STORAGE_*                                            */
+  int    plane_storage;                     /* PHOVO_STORAGE_*            yml: "plane_storage_bits: 64|32|16" */
+  int    sampling;                          /* PHOVO_SAMPLING_*           yml: "sampling_bilinear: 0|1"       */
+  int    jacobian_corrected;                /* 0 | 1                      yml: "jacobian_corrected: 0|1"      */
   int    reserved;
   double huber_delta[PHOVO_MAX_LEVELS];     /* optional yml key "huber_delta (at each level)"             */
 } phovo_extensions;
@@ -107,7 +119,8 @@ int phovo_config_read_file(const char *path, phovo_config *cfg);
 
 int phovo_extensions_default(phovo_extensions *ext);
 /* Optional keys in the same yml file (the reference's cv::FileStorage lookups ignore keys they do not ask for,
- * so such a file still loads there): "huber_delta (at each level): [..]", "plane_storage_bits: 64|32|16".
+ * so such a file still loads there): "huber_delta (at each level): [..]", "plane_storage_bits: 64|32|16",
+ * "sampling_bilinear: 0|1", "jacobian_corrected: 0|1".
  * Absent keys leave the defaults (everything off). */
 int phovo_extensions_read_file(const char *path, phovo_extensions *ext);
 

@@ -146,6 +146,56 @@ def normal_equations(planes, level, K, state, min_depth=0.3, max_depth=5.0):
     return g, Hm, r, J
 
 
+def normal_equations_bilinear(planes, level, K, state, min_depth=0.3, max_depth=5.0, corrected=False):
+    """EXTENSION (not in the reference's analytic path): forward-additive residuals / Jacobians with bilinear
+    sampling at the real-valued warped position; rows belong to the source pixel.  Returns (r[N], J[N,6])."""
+    i0, d0, i1, gx1, gy1 = planes
+    H_, W_ = i0.shape
+    sf = 1.0 / 2 ** level
+    fx, fy, ox, oy = K[0, 0] * sf, K[1, 1] * sf, K[0, 2] * sf, K[1, 2] * sf
+    x, y, z, yaw, pitch, roll = state
+    sy_, cy_, sp, cp, sr, cr = np.sin(yaw), np.cos(yaw), np.sin(pitch), np.cos(pitch), np.sin(roll), np.cos(roll)
+    R = np.array([[cy_ * cp, cy_ * sp * sr - sy_ * cr, cy_ * sp * cr + sy_ * sr],
+                  [sy_ * cp, sy_ * sp * sr + cy_ * cr, sy_ * sp * cr - cy_ * sr],
+                  [-sp, cp * sr, cp * cr]])
+    cc, rr = np.meshgrid(np.arange(W_, dtype=np.float64), np.arange(H_, dtype=np.float64))
+    pz = d0.reshape(-1)
+    valid = (min_depth < pz) & (pz < max_depth)
+    with np.errstate(all="ignore"):
+        px = (cc.reshape(-1) - ox) * pz / fx
+        py = (rr.reshape(-1) - oy) * pz / fy
+        P = R @ np.stack([px, py, pz]) + np.array([[x], [y], [z]])
+        iz = 1.0 / P[2]
+        tc, tr = P[0] * fx * iz + ox, P[1] * fy * iz + oy
+        inb = valid & (tc > -0.5) & (tc < W_ - 0.5) & (tr > -0.5) & (tr < H_ - 0.5)
+        tc, tr = np.where(inb, tc, 0.0), np.where(inb, tr, 0.0)
+        fc, fr = np.floor(tc), np.floor(tr)
+        ax, ay = tc - fc, tr - fr
+        c0, c1 = np.clip(fc, 0, W_ - 1).astype(np.int64), np.clip(fc + 1, 0, W_ - 1).astype(np.int64)
+        r0, r1 = np.clip(fr, 0, H_ - 1).astype(np.int64), np.clip(fr + 1, 0, H_ - 1).astype(np.int64)
+
+        def smp(Pl):
+            return (1 - ay) * ((1 - ax) * Pl[r0, c0] + ax * Pl[r0, c1]) + ay * ((1 - ax) * Pl[r1, c0] + ax * Pl[r1, c1])
+        res = smp(i1) - i0.reshape(-1)
+        gxs, gys = smp(gx1), smp(gy1)
+        # true derivative of the projection w.r.t. (x,y,z,yaw,pitch,roll) via the rotated point and its derivatives
+        Xr, Yr = P[0] - x, P[1] - y                        # rotated, untranslated
+        dP_dyaw = np.stack([-Yr, Xr, np.zeros_like(Xr)])
+        Zr = P[2] - z
+        dP_dpitch = np.stack([cy_ * Zr, sy_ * Zr, -(cp * px + sp * sr * py + sp * cr * pz)])
+        dP_droll = np.stack([R[0, 2] * py - R[0, 1] * pz, R[1, 2] * py - R[1, 1] * pz, R[2, 2] * py - R[2, 1] * pz])
+        Xb = P[0] if corrected else (Xr + px * x)          # the reference's slip: px*(cp*cy + x) instead of px*cp*cy + x
+        Ju = [fx * iz, 0 * iz, -fx * Xb * iz ** 2]
+        Jv = [0 * iz, fy * iz, -fy * P[1] * iz ** 2]
+        for dP in (dP_dyaw, dP_dpitch, dP_droll):
+            Ju.append(fx * dP[0] * iz - fx * Xb * dP[2] * iz ** 2)
+            Jv.append(fy * dP[1] * iz - fy * P[1] * dP[2] * iz ** 2)
+        J = np.stack([gxs * Ju[j] + gys * Jv[j] for j in range(6)], axis=1)
+    J[~inb] = 0.0
+    res = np.where(inb, res, 0.0)
+    return res, J
+
+
 def optimize(pyr, K, cfg, init_state=None):
     """cfg: dict(num_levels, lam, max_iter, min_grad, min_depth, max_depth[, huber_delta]).
     huber_delta[L] > 0 (extension, not in the reference): IRLS weights of the Huber loss.
@@ -158,8 +208,13 @@ def optimize(pyr, K, cfg, init_state=None):
         it = 0
         while True:
             if cfg["max_iter"][level] > 0:
-                g, Hm, r, J = normal_equations(pyr[level], level, K, state,
-                                               cfg.get("min_depth", 0.3), cfg.get("max_depth", 5.0))
+                if cfg.get("bilinear", False):
+                    r, J = normal_equations_bilinear(pyr[level], level, K, state, cfg.get("min_depth", 0.3),
+                                                     cfg.get("max_depth", 5.0), cfg.get("corrected", False))
+                    g, Hm = J.T @ r, J.T @ J
+                else:
+                    g, Hm, r, J = normal_equations(pyr[level], level, K, state,
+                                                   cfg.get("min_depth", 0.3), cfg.get("max_depth", 5.0))
                 delta = cfg.get("huber_delta", [0.0] * cfg["num_levels"])[level]
                 if delta > 0:
                     ar = np.abs(r)

@@ -81,6 +81,10 @@ def lib():
             C.POINTER(Config), dp, C.POINTER(Level), dp, C.POINTER(C.c_int),
             C.POINTER(TraceEntry), C.c_int, dp]
         L.phovo_oracle_optimize_huber.restype = C.c_int
+        L.phovo_oracle_optimize_ext.argtypes = [
+            C.POINTER(Config), dp, C.POINTER(Level), dp, C.POINTER(C.c_int),
+            C.POINTER(TraceEntry), C.c_int, dp, C.c_int, C.c_int]
+        L.phovo_oracle_optimize_ext.restype = C.c_int
         L.phovo_oracle_warp_image.argtypes = [
             C.c_void_p, dp, C.c_int, C.c_int, dp, dp, C.c_int, C.c_void_p]
         _lib = L
@@ -219,15 +223,23 @@ def compute_residuals_and_jacobians(i0, d0, i1, gx1, gy1, level, K, state,
 
 
 def optimize(cfg, K, i0p, d0p, i1p, gxp, gyp, init_state=None, want_trace=False,
-             trace_capacity=8192, huber_delta=None):
+             trace_capacity=8192, huber_delta=None, bilinear=False, corrected=False):
     """Optimize() on prebuilt pyramids.  Returns (state, iterations_per_level[, trace]).
-    huber_delta (per level, extension not in the reference): Huber IRLS weights where > 0."""
+    Extensions not in the reference: huber_delta (per level, Huber IRLS weights where > 0), bilinear
+    (forward-additive alignment with bilinear sampling), corrected (true Jacobian, bilinear mode)."""
     arr, keep = _levels_array(i0p, d0p, i1p, gxp, gyp)
     state = np.zeros(6) if init_state is None else _f64(init_state).copy()
     iters = (C.c_int * MAX_LEVELS)()
     Kf = _f64(K).reshape(9)
     tr = (TraceEntry * trace_capacity)() if want_trace else None
-    if huber_delta is None:
+    if bilinear or corrected:
+        hd = np.zeros(MAX_LEVELS)
+        if huber_delta is not None:
+            hd[:len(huber_delta)] = huber_delta
+        n = lib().phovo_oracle_optimize_ext(C.byref(cfg), _dp(Kf), arr, _dp(state), iters,
+                                            tr, trace_capacity if want_trace else 0, _dp(hd),
+                                            int(bool(bilinear)), int(bool(corrected)))
+    elif huber_delta is None:
         n = lib().phovo_oracle_optimize(C.byref(cfg), _dp(Kf), arr, _dp(state), iters,
                                         tr, trace_capacity if want_trace else 0)
     else:

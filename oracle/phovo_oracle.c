@@ -353,6 +353,81 @@ void phovo_oracle_compute_residuals_and_jacobians(
   }
 }
 
+/* EXTENSION, NOT IN THE REFERENCE'S ANALYTIC PATH: forward-additive residuals and Jacobians with bilinear
+ * sampling of the target intensity and gradients at the real-valued warped position.  Same warp, same temps as
+ * ComputeResidualsAndJacobians above; residual AND Jacobian row both live at the source index i (no scatter).
+ * corrected != 0 uses temp11 = cos(pitch)*cos(yaw) (the true derivative) instead of the reference's `+x`. */
+static void compute_bilinear(const phovo_oracle_level *lv, int level, const double k[9], const double state[6],
+                             double min_depth, double max_depth, int corrected,
+                             double *residuals, double *jacobians)
+{
+  const int nRows = lv->h, nCols = lv->w;
+  const size_t n = (size_t)nRows * (size_t)nCols;
+  const double scaleFactor = 1.0 / pow(2, level);
+  const double fx = k[0] * scaleFactor, fy = k[4] * scaleFactor;
+  const double ox = k[2] * scaleFactor, oy = k[5] * scaleFactor;
+  const double inv_fx = 1.f / fx, inv_fy = 1.f / fy;
+  const double x = state[0], y = state[1], z = state[2];
+  const double yaw = state[3], pitch = state[4], roll = state[5];
+  const double sy = sin(yaw), cy = cos(yaw), sp = sin(pitch), cp = cos(pitch), sr = sin(roll), cr = cos(roll);
+  const double R00 = cy * cp, R01 = cy * sp * sr - sy * cr, R02 = cy * sp * cr + sy * sr;
+  const double R10 = sy * cp, R11 = sy * sp * sr + cy * cr, R12 = sy * sp * cr - cy * sr;
+  const double temp1 = cp * sr, temp2 = cp * cr, temp3 = sp;
+  const double temp4 = (sr * sy + sp * cr * cy), temp5 = (sp * sr * cy - cr * sy);
+  const double temp6 = (sp * sr * sy + cr * cy), temp7 = (-sp * sr * sy - cr * cy);
+  const double temp8 = (sr * cy - sp * cr * sy), temp9 = (sp * cr * sy - sr * cy);
+  const double temp10 = cp * sr * cy, temp12 = cp * cr * cy, temp13 = sp * cy;
+  const double temp14 = cp * sy, temp15 = cp * cy, temp16 = sp * sr, temp17 = sp * cr;
+  const double temp18 = cp * sr * sy, temp19 = cp * cr * sy, temp20 = sp * sy;
+  const double temp21 = (cr * sy - sp * sr * cy), temp22 = cp * cr, temp23 = cp * sr, temp24 = cp;
+  for (int r = 0; r < nRows; r++) {
+    for (int c = 0; c < nCols; c++) {
+      const size_t i = (size_t)nCols * r + c;
+      const double pz = lv->d0[i];
+      if (!(min_depth < pz && pz < max_depth)) continue;
+      const double px = (c - ox) * pz * inv_fx, py = (r - oy) * pz * inv_fy;
+      const double X = ((R00 * px + R01 * py) + R02 * pz) + x;
+      const double Y = ((R10 * px + R11 * py) + R12 * pz) + y;
+      const double temp25 = 1.0 / (z + py * temp1 + pz * temp2 - px * temp3);
+      const double temp26 = temp25 * temp25;
+      const double tc = (X * fx) * temp25 + ox, tr = (Y * fy) * temp25 + oy;
+      /* in bounds iff the nearest pixel is inside (the region of the reference's round() test); taps are
+       * clamped to the edge row / column in the outer half-pixel band */
+      if (!(tc > -0.5 && tc < (double)nCols - 0.5 && tr > -0.5 && tr < (double)nRows - 0.5)) continue;
+      const double fc = floor(tc), fr = floor(tr);
+      const double ax = tc - fc, ay = tr - fr;
+      const int ic = (int)fc, ir = (int)fr;
+      const int c0 = ic < 0 ? 0 : ic, c1 = ic + 1 > nCols - 1 ? nCols - 1 : ic + 1;
+      const int r0 = ir < 0 ? 0 : ir, r1 = ir + 1 > nRows - 1 ? nRows - 1 : ir + 1;
+      double smp[3];
+      const double *pl[3] = {lv->i1, lv->gx1, lv->gy1};
+      for (int q = 0; q < 3; q++) {
+        const double *P = pl[q];
+        smp[q] = (1.0 - ay) * ((1.0 - ax) * P[(size_t)r0 * nCols + c0] + ax * P[(size_t)r0 * nCols + c1]) +
+                 ay * ((1.0 - ax) * P[(size_t)r1 * nCols + c0] + ax * P[(size_t)r1 * nCols + c1]);
+      }
+      const double A = corrected ? (pz * temp4 + py * temp5 + px * temp15 + x)
+                                 : (pz * temp4 + py * temp5 + px * (temp15 + x));
+      const double B = (py * temp6 + pz * temp9 + px * temp14 + y);
+      const double Cc = (-py * temp16 - pz * temp17 - px * temp24);
+      const double D = (py * temp22 - pz * temp23);
+      double J[2][6];
+      J[0][0] = fx * temp25;  J[1][0] = 0.0;
+      J[0][1] = 0.0;          J[1][1] = fy * temp25;
+      J[0][2] = -fx * A * temp26;
+      J[1][2] = -fy * B * temp26;
+      J[0][3] = fx * (py * temp7 + pz * temp8 - px * temp14) * temp25;
+      J[1][3] = fy * (pz * temp4 + py * temp5 + px * temp15) * temp25;
+      J[0][4] = fx * (py * temp10 + pz * temp12 - px * temp13) * temp25 - fx * Cc * A * temp26;
+      J[1][4] = fy * (py * temp18 + pz * temp19 - px * temp20) * temp25 - fy * Cc * B * temp26;
+      J[0][5] = fx * (py * temp4 + pz * temp21) * temp25 - fx * D * A * temp26;
+      J[1][5] = fy * (pz * temp7 + py * temp9) * temp25 - fy * D * B * temp26;
+      for (int j = 0; j < 6; j++) jacobians[(size_t)j * n + i] = smp[1] * J[0][j] + smp[2] * J[1][j];
+      residuals[i] = smp[0] - lv->i0[i];
+    }
+  }
+}
+
 /* 6x6 inverse by LU with partial pivoting (Eigen's fixed-size .inverse() for
  * sizes > 4 goes through PartialPivLU; ...Analytic.h:540). */
 static void inverse6(const double a[36], double inv[36])
@@ -402,14 +477,14 @@ static int optimize_impl(const phovo_oracle_config *cfg, const double k[9],
                          const phovo_oracle_level *levels, double state[6],
                          int *iterations_per_level,
                          phovo_oracle_trace_entry *trace, int trace_capacity,
-                         const double *huber_delta);
+                         const double *huber_delta, int bilinear, int corrected);
 
 int phovo_oracle_optimize(const phovo_oracle_config *cfg, const double k[9],
                           const phovo_oracle_level *levels, double state[6],
                           int *iterations_per_level,
                           phovo_oracle_trace_entry *trace, int trace_capacity)
 {
-  return optimize_impl(cfg, k, levels, state, iterations_per_level, trace, trace_capacity, NULL);
+  return optimize_impl(cfg, k, levels, state, iterations_per_level, trace, trace_capacity, NULL, 0, 0);
 }
 
 /* EXTENSION, NOT IN THE REFERENCE (BASELINE.json configs[4]): Optimize() with Huber IRLS weights.  Row k of the
@@ -421,14 +496,25 @@ int phovo_oracle_optimize_huber(const phovo_oracle_config *cfg, const double k[9
                                 phovo_oracle_trace_entry *trace, int trace_capacity,
                                 const double *huber_delta)
 {
-  return optimize_impl(cfg, k, levels, state, iterations_per_level, trace, trace_capacity, huber_delta);
+  return optimize_impl(cfg, k, levels, state, iterations_per_level, trace, trace_capacity, huber_delta, 0, 0);
+}
+
+/* EXTENSION, NOT IN THE REFERENCE: all opt-in modes at once (Huber deltas may be NULL). */
+int phovo_oracle_optimize_ext(const phovo_oracle_config *cfg, const double k[9],
+                              const phovo_oracle_level *levels, double state[6],
+                              int *iterations_per_level,
+                              phovo_oracle_trace_entry *trace, int trace_capacity,
+                              const double *huber_delta, int bilinear, int corrected)
+{
+  return optimize_impl(cfg, k, levels, state, iterations_per_level, trace, trace_capacity, huber_delta, bilinear,
+                       corrected);
 }
 
 static int optimize_impl(const phovo_oracle_config *cfg, const double k[9],
                          const phovo_oracle_level *levels, double state[6],
                          int *iterations_per_level,
                          phovo_oracle_trace_entry *trace, int trace_capacity,
-                         const double *huber_delta)
+                         const double *huber_delta, int bilinear, int corrected)
 {
   double gradients[6] = {0, 0, 0, 0, 0, 0};    /* m_Gradients persists across levels */
   int executed = 0;
@@ -446,8 +532,11 @@ static int optimize_impl(const phovo_oracle_config *cfg, const double k[9],
       memset(jacobians, 0, sizeof(double) * nPoints * 6);
 
       if (cfg->max_num_iterations[level] > 0) {                         /* :526 */
-        phovo_oracle_compute_residuals_and_jacobians(lv, level, k, state,
-            cfg->min_depth, cfg->max_depth, residuals, jacobians, NULL);
+        if (bilinear)
+          compute_bilinear(lv, level, k, state, cfg->min_depth, cfg->max_depth, corrected, residuals, jacobians);
+        else
+          phovo_oracle_compute_residuals_and_jacobians(lv, level, k, state,
+              cfg->min_depth, cfg->max_depth, residuals, jacobians, NULL);
 
         double H[36];
         const double delta = huber_delta ? huber_delta[level] : 0.0;

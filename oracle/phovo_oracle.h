@@ -113,6 +113,13 @@ int phovo_oracle_optimize_huber(const phovo_oracle_config *cfg, const double k[9
                                 phovo_oracle_trace_entry *trace, int trace_capacity,
                                 const double *huber_delta);
 
+/* EXTENSION, NOT IN THE REFERENCE: + bilinear forward-additive sampling, optionally with the corrected Jacobian. */
+int phovo_oracle_optimize_ext(const phovo_oracle_config *cfg, const double k[9],
+                              const phovo_oracle_level *levels, double state[6],
+                              int *iterations_per_level,
+                              phovo_oracle_trace_entry *trace, int trace_capacity,
+                              const double *huber_delta, int bilinear, int corrected);
+
 /* CPhotoconsistencyOdometry.h:73-134 (truncating cast, depth>0 gate). */
 void phovo_oracle_warp_image(const uint8_t *intensity, const double *depth,
                              int w, int h, const double rt[16], const double k[9],

@@ -397,6 +397,11 @@ int phovo_engine_set_extensions(phovo_engine *e, const phovo_extensions *ext)
   if (ext->plane_storage != PHOVO_STORAGE_F64 && ext->plane_storage != PHOVO_STORAGE_F32 &&
       ext->plane_storage != PHOVO_STORAGE_F16)
     return fail(PHOVO_E_INVALID_ARGUMENT, "set_extensions: unknown plane_storage");
+  if (ext->sampling != PHOVO_SAMPLING_NEAREST_SCATTER && ext->sampling != PHOVO_SAMPLING_BILINEAR)
+    return fail(PHOVO_E_INVALID_ARGUMENT, "set_extensions: unknown sampling");
+  if (ext->jacobian_corrected != 0 && ext->sampling != PHOVO_SAMPLING_BILINEAR)
+    return fail(PHOVO_E_UNSUPPORTED, "set_extensions: jacobian_corrected needs sampling = PHOVO_SAMPLING_BILINEAR "
+                                     "(the scatter path is kept reference-exact)");
   for (int l = 0; l < PHOVO_MAX_LEVELS; l++)
     if (!(ext->huber_delta[l] == ext->huber_delta[l])) return fail(PHOVO_E_INVALID_ARGUMENT, "set_extensions: huber_delta is NaN");
   if (ext->plane_storage != e->ext.plane_storage) {      // the pool layout changes
@@ -707,6 +712,7 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
     if (e->cfg.max_num_iterations[l] <= 0) continue;
     const LevelPool &lv = e->levels[l];
     if (!lv.stored) return fail(PHOVO_E_NOT_READY, "align: an active level is not resident");
+    if (e->ext.sampling == PHOVO_SAMPLING_BILINEAR) continue;       // no owner map, no LDS limit
     if (!lv.plan_ok) return fail(PHOVO_E_SHAPE, "align: pyramid level too large for the device path (in-bounds mask exceeds LDS)");
     if (!lv.plan.owner_in_lds) {
       const size_t need = (size_t)n_pairs * (size_t)lv.n;
@@ -751,7 +757,10 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
     a.states = e->d_states; a.reports = e->d_reports;
     a.g_owner = e->d_owner;
     PHOVO_HIP_CHECK(hipEventRecord(e->ev_start[l], e->stream));
-    PHOVO_HIP_CHECK(gn_launch_level(a, lv.plan, e->ext.plane_storage, n_pairs, e->stream));
+    if (e->ext.sampling == PHOVO_SAMPLING_BILINEAR)
+      PHOVO_HIP_CHECK(gn_launch_level_bilinear(a, e->ext.plane_storage, e->ext.jacobian_corrected != 0, n_pairs, e->stream));
+    else
+      PHOVO_HIP_CHECK(gn_launch_level(a, lv.plan, e->ext.plane_storage, n_pairs, e->stream));
     PHOVO_HIP_CHECK(hipEventRecord(e->ev_stop[l], e->stream));
     e->level_launched[l] = true;
   }

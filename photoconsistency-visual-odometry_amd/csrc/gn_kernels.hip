@@ -555,6 +555,219 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
   }
 }
 
+// Wave butterfly + cross-wave sum + solve + update + termination, as in gn_level_kernel's tail, for kernels
+// that keep their 27 sums in `acc`.  Returns after the closing barrier; the caller reads s_ctl[CTL_DONE].
+template <int NW>
+__device__ __forceinline__ void reduce_solve_update(double (&acc)[NRED], int lane, int wave, double *s_red,
+                                                    double *s_state, double *s_cst, int *s_ctl,
+                                                    double lambda, int max_iter, double min_grad_norm,
+                                                    int iteration, double &last_gnorm)
+{
+  reduce_stage_swap<32, false>(acc);
+  reduce_stage_swap<16, true>(acc);
+  reduce_stage<8, 4>(acc, lane, 8);
+  reduce_stage<4, 4>(acc, lane, 4);
+  reduce_stage<2, 4>(acc, lane, 2);
+  {
+    const double total = acc[0] + __shfl_xor(acc[0], 1, WAVE);
+    const int idx = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 +
+                    ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+    if ((lane & 1) == 0) s_red[wave * NRED + idx] = total;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    double v = 0.0;
+    {
+      const int j = lane & (NRED - 1);
+      const int w0 = (lane >> 5) * (NW / 2);
+#pragma unroll
+      for (int w2 = 0; w2 < NW / 2; w2++) v += s_red[(w0 + w2) * NRED + j];
+      v += __shfl_xor(v, 32, WAVE);
+    }
+    double h[21], g[6];
+#pragma unroll
+    for (int q = 0; q < 21; q++) h[q] = __shfl(v, q, WAVE);
+#pragma unroll
+    for (int i = 0; i < 6; i++) g[i] = __shfl(v, 21 + i, WAVE);
+    double step[6];
+    solve6_ldlt(h, g, step);
+    double st[6];
+    bool finite = true;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      st[i] = s_state[i] - lambda * step[i];                                            // :539
+      finite = finite && (fabs(st[i]) <= 1.79769313486231570815e308);
+    }
+    double gn2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) gn2 += g[i] * g[i];
+    const double gnorm = sqrt(gn2);                                                     // :380
+    bool done = false;
+    if (iteration + 1 >= max_iter) done = true;                                         // :383
+    else if (gnorm < min_grad_norm) done = true;                                        // :388
+    if (!finite) done = true;
+    if (!done) write_pose_constants(st[0], st[1], st[2], st[3], st[4], st[5], s_cst, lane);
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) s_state[i] = st[i];
+      s_ctl[CTL_DONE] = done ? 1 : 0;
+      if (!finite) s_ctl[CTL_FLAGS] |= (int)PHOVO_PAIR_NONFINITE;
+    }
+    last_gnorm = gnorm;
+  }
+  __syncthreads();
+}
+
+// EXTENSION, NOT IN THE REFERENCE'S ANALYTIC PATH (PHOVO_SAMPLING_BILINEAR): forward-additive alignment with
+// bilinear sampling.  Every valid source pixel i is warped to the real-valued (tr, tc); the target intensity and
+// its two gradients are sampled bilinearly there (clamp-to-edge taps; in bounds iff the nearest pixel is), the residual
+// r_i = I1(tr,tc) - I0(i) and the Jacobian row J_i = gx(tr,tc)*Ju + gy(tr,tc)*Jv both belong to source pixel i.
+// No scatter, hence no owner map and a single pass per iteration.  CORRECTED selects the true warp Jacobian
+// (temp11 = temp15, i.e. without the reference's `+x` transcription slip, ...Analytic.h:253) instead of the
+// reference's.  Huber weights and narrow storages combine with it.  The reference's only bilinear sampler lives in
+// its Ceres path (third_party/sample.h:53-99, out of scope); this one uses pixel-centre integer coordinates like
+// the analytic path's round().
+template <int T, int WPS, typename TI, typename TD, bool CORRECTED>
+__global__ __launch_bounds__(T, WPS) void gn_level_kernel_bilinear(const GNLevelArgs A)
+{
+  constexpr int NW = T / WAVE;
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  double *s_cst = reinterpret_cast<double *>(lds_raw);                 // [32]
+  double *s_state = s_cst + 32;                                        // [8]
+  double *s_red = s_state + 8;                                         // [NW][NRED]
+  int *s_ctl = reinterpret_cast<int *>(s_red + NW * NRED);             // [CTL_COUNT]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & (WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
+  const int pair = blockIdx.x;
+  const int n = A.n, W = A.w, H = A.h;
+  const unsigned char *src_frame = A.planes + (size_t)A.src[pair] * A.frame_bytes;
+  const unsigned char *tgt_frame = A.planes + (size_t)A.tgt[pair] * A.frame_bytes;
+  const __amdgpu_buffer_rsrc_t rI0 = plane_rsrc<TI>(src_frame + A.plane_off[PLANE_I], n);
+  const __amdgpu_buffer_rsrc_t rD0 = plane_rsrc<TD>(src_frame + A.plane_off[PLANE_D], n);
+  const __amdgpu_buffer_rsrc_t rI1 = plane_rsrc<TI>(tgt_frame + A.plane_off[PLANE_I], n);
+  const __amdgpu_buffer_rsrc_t rGX = plane_rsrc<TI>(tgt_frame + A.plane_off[PLANE_GX], n);
+  const __amdgpu_buffer_rsrc_t rGY = plane_rsrc<TI>(tgt_frame + A.plane_off[PLANE_GY], n);
+
+  if (wave == 0) {
+    double st[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) st[j] = A.states[(size_t)pair * 6 + j];
+    write_pose_constants(st[0], st[1], st[2], st[3], st[4], st[5], s_cst, lane);
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < 6; j++) s_state[j] = st[j];
+      s_ctl[CTL_DONE] = 0;
+      s_ctl[CTL_FLAGS] = 0;
+    }
+  }
+  __syncthreads();
+
+  const double fx = A.fx, fy = A.fy, ox = A.ox, oy = A.oy, ifx = A.ifx, ify = A.ify;
+  const double min_d = A.min_depth, max_d = A.max_depth;
+  const double wlim = (double)W - 0.5, hlim = (double)H - 0.5;
+  const double huber_delta = A.huber_delta;
+  const bool huber_on = huber_delta > 0.0;
+  const int k0 = wave * WAVE + lane;
+  const int r0 = k0 / W, c0 = k0 - r0 * W;
+  const int step_r = (NW * WAVE) / W, step_c = (NW * WAVE) - step_r * W;
+
+  int iteration = 0;
+  double last_gnorm = 0.0;
+  while (true) {
+    const double cx = uniform_f64(s_cst[C_X]), cyy = uniform_f64(s_cst[C_Y]), cz = uniform_f64(s_cst[C_Z]);
+    const double r01 = uniform_f64(s_cst[C_R01]), r02 = uniform_f64(s_cst[C_R02]);
+    const double r11 = uniform_f64(s_cst[C_R11]), r12 = uniform_f64(s_cst[C_R12]);
+    const double t1 = uniform_f64(s_cst[C_T1]), t2 = uniform_f64(s_cst[C_T2]), t3 = uniform_f64(s_cst[C_T3]);
+    const double t4 = uniform_f64(s_cst[C_T4]), t5 = uniform_f64(s_cst[C_T5]), t6 = uniform_f64(s_cst[C_T6]);
+    const double t8 = uniform_f64(s_cst[C_T8]), t14 = uniform_f64(s_cst[C_T14]), t15 = uniform_f64(s_cst[C_T15]);
+    const double t16 = uniform_f64(s_cst[C_T16]), t17 = uniform_f64(s_cst[C_T17]), t24 = uniform_f64(s_cst[C_T24]);
+    const double cosy = uniform_f64(s_cst[C_CY]), siny = uniform_f64(s_cst[C_SY]);
+    const double t7 = -t6, t9 = -t8, t21 = -t5;
+
+    double acc[NRED];
+#pragma unroll
+    for (int j = 0; j < NRED; j++) acc[j] = 0.0;
+
+    int k = k0, r = r0, c = c0;
+    for (int chunk = wave; chunk < A.n_chunks; chunk += NW) {
+      const double pz = plane_load<TD>(rD0, k);                           // past the plane: 0
+      if (k < n && min_d < pz && pz < max_d) {                            // :280
+        const double px = ((double)c - ox) * pz * ifx;                    // :282
+        const double py = ((double)r - oy) * pz * ify;                    // :283
+        const double X = ((t15 * px + r01 * py) + r02 * pz) + cx;         // :291
+        const double Y = ((t14 * px + r11 * py) + r12 * pz) + cyy;
+        const double Zr = py * t1 + pz * t2 - px * t3;
+        const double t25 = fast_rcp(cz + Zr);                             // :294 and :313 are the same quantity
+        const double tc = (X * fx) * t25 + ox;                            // :295
+        const double tr = (Y * fy) * t25 + oy;                            // :296
+        // In bounds iff the NEAREST pixel is inside -- the same region as the reference's round() test
+        // (:297-303), so a zero-motion start never sits on the boundary; in the outer half-pixel band the
+        // taps are clamped to the edge row / column (NaN fails the comparisons).
+        if (tc > -0.5 && tc < wlim && tr > -0.5 && tr < hlim) {
+          const double fc = floor(tc), fr = floor(tr);
+          const double ax = tc - fc, ay = tr - fr;
+          const int ic = (int)fc, ir = (int)fr;
+          const int c0i = max(ic, 0), c1i = min(ic + 1, W - 1);
+          const int r0w = __mul24(max(ir, 0), W), r1w = __mul24(min(ir + 1, H - 1), W);
+          auto sample = [&](__amdgpu_buffer_rsrc_t rs) {
+            const double p00 = plane_load<TI>(rs, r0w + c0i), p01 = plane_load<TI>(rs, r0w + c1i);
+            const double p10 = plane_load<TI>(rs, r1w + c0i), p11 = plane_load<TI>(rs, r1w + c1i);
+            return (1.0 - ay) * ((1.0 - ax) * p00 + ax * p01) + ay * ((1.0 - ax) * p10 + ax * p11);
+          };
+          const double res = sample(rI1) - plane_load<TI>(rI0, k);
+          const double gxi = sample(rGX), gyi = sample(rGY);
+
+          const double base = pz * t4 + py * t5 + px * t15;               // (pz*temp4+py*temp5+px*temp15) = X - x
+          const double Au = CORRECTED ? base + cx : base + px * cx;       // reference: px*(temp15 + x)  (:253)
+          const double Bv = py * t6 + pz * t9 + px * t14 + cyy;
+          const double Cm = -py * t16 - pz * t17 - px * t24;
+          const double Dm = py * t2 - pz * t1;
+          double J[6];
+          J[0] = (gxi * fx) * t25;
+          J[1] = (gyi * fy) * t25;
+          J[2] = -(J[0] * Au + J[1] * Bv) * t25;
+          J[3] = J[0] * (cyy - Bv) + J[1] * base;
+          J[4] = (J[0] * cosy + J[1] * siny) * Zr + Cm * J[2];
+          J[5] = J[0] * (py * t4 + pz * t21) + J[1] * (pz * t7 + py * t9) + Dm * J[2];
+          double wgt = 1.0;
+          if (huber_on) {
+            const double ar = fabs(res);
+            wgt = ar <= huber_delta ? 1.0 : huber_delta / ar;
+          }
+          int q = 0;
+#pragma unroll
+          for (int a = 0; a < 6; a++) {
+            const double jw = J[a] * wgt;
+#pragma unroll
+            for (int b = a; b < 6; b++) {
+              acc[q] = fma(jw, J[b], acc[q]);
+              q++;
+            }
+            acc[21 + a] = fma(jw, res, acc[21 + a]);
+          }
+        }
+      }
+      k += NW * WAVE; c += step_c; r += step_r;
+      if (c >= W) { c -= W; r += 1; }
+    }
+    reduce_solve_update<NW>(acc, lane, wave, s_red, s_state, s_cst, s_ctl, A.lambda, A.max_iter, A.min_grad_norm,
+                            iteration, last_gnorm);
+    iteration++;
+    if (s_ctl[CTL_DONE]) break;
+  }
+  if (tid == 0) {
+#pragma unroll
+    for (int j = 0; j < 6; j++) A.states[(size_t)pair * 6 + j] = s_state[j];
+    if (A.reports) {
+      A.reports[pair].iterations[A.level] = iteration;
+      A.reports[pair].gradient_norm = last_gnorm;
+      A.reports[pair].flags |= (uint32_t)s_ctl[CTL_FLAGS];
+    }
+  }
+}
+
 constexpr size_t LDS_LIMIT = 160 * 1024;   // MI355X: 160 KiB per CU, one workgroup may take all of it
 constexpr size_t LDS_HALF = LDS_LIMIT / 2; // two workgroups per CU
 
@@ -652,6 +865,28 @@ hipError_t launch_storage(const GNLevelArgs &a, const GNLaunchPlan &plan, int n_
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
+}
+
+template <typename TI, typename TD>
+hipError_t launch_bilinear_storage(const GNLevelArgs &a, bool corrected, int n_pairs, hipStream_t stream)
+{
+  const dim3 grid((unsigned)n_pairs), block(256);
+  const size_t lds = lds_fixed_bytes(256);
+  if (corrected) hipLaunchKernelGGL((gn_level_kernel_bilinear<256, 4, TI, TD, true>), grid, block, lds, stream, a);
+  else hipLaunchKernelGGL((gn_level_kernel_bilinear<256, 4, TI, TD, false>), grid, block, lds, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t gn_launch_level_bilinear(const GNLevelArgs &a, int storage, bool corrected, int n_pairs,
+                                    hipStream_t stream)
+{
+  if (n_pairs <= 0) return hipSuccess;
+  switch (storage) {
+    case PHOVO_STORAGE_F64: return launch_bilinear_storage<double, double>(a, corrected, n_pairs, stream);
+    case PHOVO_STORAGE_F32: return launch_bilinear_storage<float, float>(a, corrected, n_pairs, stream);
+    case PHOVO_STORAGE_F16: return launch_bilinear_storage<__half, float>(a, corrected, n_pairs, stream);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 hipError_t gn_prepare_kernels()

@@ -48,6 +48,9 @@ struct GNLaunchPlan {
 bool gn_plan_level(int n, GNLaunchPlan *plan);
 hipError_t gn_launch_level(const GNLevelArgs &args, const GNLaunchPlan &plan, int storage, int n_pairs,
                            hipStream_t stream);
+// Extension (PHOVO_SAMPLING_BILINEAR): single-pass kernel, 256 threads, no owner map, any level size.
+hipError_t gn_launch_level_bilinear(const GNLevelArgs &args, int storage, bool corrected, int n_pairs,
+                                    hipStream_t stream);
 hipError_t gn_prepare_kernels();   // raises the dynamic-LDS limit of every instantiation
 
 // Pyramid producers (SetSourceFrame / SetTargetFrame, ...Analytic.h:466-491), batched over `frames`

@@ -185,6 +185,11 @@ int read_extensions_file(const char *path, phovo_extensions *ext)
       else if (v[0] == 32) e.plane_storage = PHOVO_STORAGE_F32;
       else if (v[0] == 16) e.plane_storage = PHOVO_STORAGE_F16;
       else return fail(PHOVO_E_CONFIG, "plane_storage_bits must be 64, 32 or 16");
+    } else if (key == "sampling_bilinear" || key == "jacobian_corrected") {
+      if (!parse_values(t.substr(colon + 1), &v) || v.size() != 1 || (v[0] != 0 && v[0] != 1))
+        return fail(PHOVO_E_CONFIG, "configuration key malformed: '" + key + "' must be 0 or 1");
+      if (key == "sampling_bilinear") e.sampling = v[0] != 0 ? PHOVO_SAMPLING_BILINEAR : PHOVO_SAMPLING_NEAREST_SCATTER;
+      else e.jacobian_corrected = v[0] != 0 ? 1 : 0;
     }
   }
   *ext = e;

@@ -36,11 +36,14 @@ class Config(C.Structure):
 
 
 STORAGE_F64, STORAGE_F32, STORAGE_F16 = 0, 1, 2
+SAMPLING_NEAREST_SCATTER, SAMPLING_BILINEAR = 0, 1
 
 
 class Extensions(C.Structure):
     _fields_ = [
         ("plane_storage", C.c_int),
+        ("sampling", C.c_int),
+        ("jacobian_corrected", C.c_int),
         ("reserved", C.c_int),
         ("huber_delta", C.c_double * MAX_LEVELS),
     ]
@@ -173,10 +176,13 @@ def make_config(num_levels=None, blur=None, grad_scale=None, lam=None, max_iter=
     return cfg
 
 
-def make_extensions(plane_storage=STORAGE_F64, huber_delta=None):
+def make_extensions(plane_storage=STORAGE_F64, huber_delta=None, sampling=SAMPLING_NEAREST_SCATTER,
+                    jacobian_corrected=False):
     ext = Extensions()
     check(lib().phovo_extensions_default(C.byref(ext)), "phovo_extensions_default")
     ext.plane_storage = int(plane_storage)
+    ext.sampling = int(sampling)
+    ext.jacobian_corrected = int(bool(jacobian_corrected))
     if huber_delta is not None:
         for i, v in enumerate(list(huber_delta)[:MAX_LEVELS]):
             ext.huber_delta[i] = float(v)

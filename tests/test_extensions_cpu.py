@@ -72,3 +72,39 @@ def test_extension_keys_are_optional_in_the_yml(tmp_path):
     with pytest.raises(native.PhovoError) as ei:
         native.read_extensions_file(str(bad))
     assert ei.value.status == 2
+
+
+@pytest.mark.parametrize("corrected", [False, True])
+def test_oracle_bilinear_matches_twin(corrected):
+    """Bilinear forward-additive mode: the oracle (reference temps, optional `+x` slip) against the twin, which
+    builds the Jacobian from the rotated point's derivatives instead -- two derivations, one answer."""
+    p = synthetic.make_pair(31, 96, 72, holes=0.03)
+    nl, mi = 3, [3, 5, 8]
+    ocfg = oracle.make_config(num_levels=nl, max_iter=mi, min_grad=[0.0] * nl)
+    i0p, d0p = oracle.build_source_pyramids(p["gray0"], p["depth0"], ocfg)
+    i1p, gxp, gyp = oracle.build_target_pyramids(p["gray1"], ocfg)
+    pyr = twin.build_pyramids(p["gray0"], p["depth0"], p["gray1"], nl, [0.0625] * nl)
+    s1, it1, tr1 = oracle.optimize(ocfg, p["K"], i0p, d0p, i1p, gxp, gyp, want_trace=True,
+                                   bilinear=True, corrected=corrected, huber_delta=[0.0, 0.03, 0.03])
+    s2, it2, tr2 = twin.optimize(pyr, p["K"], dict(num_levels=nl, lam=[1.0] * nl, max_iter=mi, min_grad=[0.0] * nl,
+                                                    bilinear=True, corrected=corrected, huber_delta=[0.0, 0.03, 0.03]))
+    assert it1 == it2
+    for a, b in zip(tr1, tr2):
+        np.testing.assert_allclose(a["gradient"], b["gradient"], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(a["hessian"], b["hessian"], rtol=1e-9, atol=1e-8)
+    assert se3.state_distance(s1, s2) < 1e-9
+    # and it is the better estimator on this synthetic pair than the reference's nearest/scatter formulation
+    s0, _ = oracle.optimize(ocfg, p["K"], i0p, d0p, i1p, gxp, gyp)
+    assert se3.state_distance(s1, p["motion"]) < se3.state_distance(s0, p["motion"])
+
+
+def test_sampling_keys_in_yml(tmp_path):
+    base = open(os.path.join(CFG, "config_4_level_optimization_analytic.yml")).read()
+    p = tmp_path / "b.yml"
+    p.write_text(base + "sampling_bilinear: 1\njacobian_corrected: 1\n")
+    ext = native.read_extensions_file(str(p))
+    assert ext.sampling == native.SAMPLING_BILINEAR and ext.jacobian_corrected == 1
+    bad = tmp_path / "bad2.yml"
+    bad.write_text(base + "sampling_bilinear: 2\n")
+    with pytest.raises(native.PhovoError):
+        native.read_extensions_file(str(bad))

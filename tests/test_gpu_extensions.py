@@ -144,3 +144,57 @@ def test_config5_shape_huber_fp16_through_yml_and_class_surface(tmp_path):
         rep = po.GetReport()
     assert list(rep.iterations[:nl]) == eits
     assert se3.state_distance(s, es) < POSE_TOL
+
+
+@pytest.mark.parametrize("corrected,storage,huber", [
+    (False, native.STORAGE_F64, None),
+    (True, native.STORAGE_F64, None),
+    (True, native.STORAGE_F16, [0.0, 0.0, 0.05, 0.05]),
+])
+def test_bilinear_sampling_matches_extended_oracle(corrected, storage, huber):
+    """PHOVO_SAMPLING_BILINEAR (single-pass kernel, no owner map) against the oracle's bilinear mode, alone and
+    combined with the corrected Jacobian, fp16 storage and Huber weights."""
+    p = synthetic.make_pair(24, 640, 480, holes=0.02)
+    ncfg, ocfg, nl, mi = _cfg_pair("config_4_level_optimization_analytic.yml", fixed_cap=10)
+    with odometry.AlignmentEngine() as eng:
+        eng.set_config(ncfg)
+        eng.set_extensions(native.make_extensions(plane_storage=storage, huber_delta=huber,
+                                                  sampling=native.SAMPLING_BILINEAR, jacobian_corrected=corrected))
+        eng.set_intrinsic_matrix(p["K"])
+        eng.reserve_frames(2, 640, 480)
+        eng.upload_frame(0, p["gray0"], p["depth0"])
+        eng.upload_frame(1, p["gray1"], p["depth1"])
+        planes = _stored_planes(eng, 0, 1, nl, mi, 640, 480)
+        s, reps = eng.align_pairs([0, 0], [1, 1], want_reports=True)
+    es, eits, etr = oracle.optimize(ocfg, p["K"], *planes, want_trace=True, huber_delta=huber,
+                                    bilinear=True, corrected=corrected)
+    assert list(reps[0].iterations[:nl]) == eits
+    assert se3.state_distance(s[0], es) < POSE_TOL
+    assert np.array_equal(s[0], s[1])
+    # bilinear alignment converges: the last gradient is a small difference of large sums, so the fp64 noise of the
+    # sums (relative to the FIRST gradient's size) is what bounds the error, not the last gradient's own size
+    g_last = np.linalg.norm(etr[-1]["gradient"])
+    g_scale = max(np.linalg.norm(e["gradient"]) for e in etr)
+    assert abs(reps[0].gradient_norm - g_last) <= 1e-8 * max(1.0, g_scale)
+
+
+def test_bilinear_handles_levels_of_any_size_and_rejects_bad_combinations():
+    p = synthetic.make_pair(25, 640, 480, holes=0.01, trans=0.004, rot=0.002)
+    ncfg = native.make_config(num_levels=1, max_iter=[5], min_grad=[0.0])        # 307200 px in one level
+    ocfg = oracle.make_config(num_levels=1, max_iter=[5], min_grad=[0.0])
+    i0p, d0p = oracle.build_source_pyramids(p["gray0"], p["depth0"], ocfg)
+    i1p, gxp, gyp = oracle.build_target_pyramids(p["gray1"], ocfg)
+    es, eits = oracle.optimize(ocfg, p["K"], i0p, d0p, i1p, gxp, gyp, bilinear=True, corrected=True)
+    with odometry.AlignmentEngine() as eng:
+        eng.set_config(ncfg)
+        eng.set_extensions(native.make_extensions(sampling=native.SAMPLING_BILINEAR, jacobian_corrected=True))
+        eng.set_intrinsic_matrix(p["K"])
+        eng.reserve_frames(2, 640, 480)
+        eng.upload_frame(0, p["gray0"], p["depth0"])
+        eng.upload_frame(1, p["gray1"], p["depth1"])
+        s, reps = eng.align_pairs([0], [1], want_reports=True)
+        with pytest.raises(native.PhovoError) as ei:         # the scatter path stays reference-exact
+            eng.set_extensions(native.make_extensions(jacobian_corrected=True))
+        assert ei.value.status == 7
+    assert list(reps[0].iterations[:1]) == eits
+    assert se3.state_distance(s[0], es) < POSE_TOL
