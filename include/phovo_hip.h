@@ -173,6 +173,15 @@ int phovo_engine_set_depth_range(phovo_engine *e, double min_depth, double max_d
  * never read by Optimize()).  1: every level, as the reference does (:474-475,487-490). */
 int phovo_engine_set_build_all_levels(phovo_engine *e, int on);
 
+/* How a level is run.  The persistent form gives every pair ONE workgroup for all iterations of a level (the
+ * throughput form).  The wide form cuts a pair into tiles of 1024 pixels, one workgroup each, with three launches
+ * per iteration and a host look at the "done" words every 8 iterations (the latency form for a handful of pairs on
+ * a large level; reference-exact configuration only).  policy: 0 = automatic (wide iff n_pairs <= 32 and the level
+ * has >= 16384 pixels), 1 = wide wherever possible, -1 = never.  Results are the same either way. */
+int phovo_engine_set_wide_policy(phovo_engine *e, int policy);
+/* 1 if `level` would run in the wide form for a batch of n_pairs under the current settings. */
+int phovo_engine_level_uses_wide(const phovo_engine *e, int level, int n_pairs);
+
 /* (Re)allocates the frame pool: n_frames frames of width x height.  Uses the current config. */
 int phovo_engine_reserve_frames(phovo_engine *e, int n_frames, int width, int height);
 int phovo_engine_level_size(const phovo_engine *e, int level, int *width, int *height);

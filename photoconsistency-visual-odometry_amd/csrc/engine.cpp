@@ -76,6 +76,10 @@ struct phovo_engine {
   phovo_pair_report *d_reports = nullptr;
   int *d_owner = nullptr;
   size_t owner_capacity = 0;
+  void *d_wide_ws = nullptr;                   // workspace of the wide (many-workgroups-per-pair) level form
+  size_t wide_ws_capacity = 0;
+  std::vector<int> h_wide_done;
+  int wide_policy = 0;                         // 0 auto, 1 always (where possible), -1 never
   int last_pairs = 0;
 };
 
@@ -107,6 +111,8 @@ void free_pairs(phovo_engine *e)
   if (e->d_states) (void)hipFree(e->d_states);
   if (e->d_reports) (void)hipFree(e->d_reports);
   if (e->d_owner) (void)hipFree(e->d_owner);
+  if (e->d_wide_ws) (void)hipFree(e->d_wide_ws);
+  e->d_wide_ws = nullptr; e->wide_ws_capacity = 0;
   e->d_src = e->d_tgt = nullptr; e->d_states = nullptr; e->d_reports = nullptr; e->d_owner = nullptr;
   e->pair_capacity = 0; e->owner_capacity = 0;
 }
@@ -132,14 +138,26 @@ void level_dims(int w, int h, int level, int *lw, int *lh)
   *lh = (int)std::rint((double)h * f);
 }
 
+// A handful of pairs on a large level: cut every pair into many workgroups (gn_wide_kernels.hip) instead of
+// giving it one.  Only the reference-exact configuration (fp64 planes, no extension) takes this form.
+bool use_wide_level(const phovo_engine *e, int n_pairs, int n_pixels)
+{
+  if (e->wide_policy < 0) return false;
+  if (e->ext.plane_storage != PHOVO_STORAGE_F64 || e->ext.sampling != PHOVO_SAMPLING_NEAREST_SCATTER) return false;
+  if (e->wide_policy > 0) return true;
+  return n_pairs * 8 <= 256 && n_pixels >= 16384;
+}
+
 int ensure_pairs(phovo_engine *e, int n_pairs)
 {
   if (n_pairs <= e->pair_capacity) return PHOVO_OK;
-  const size_t keep_owner = e->owner_capacity;
+  const size_t keep_owner = e->owner_capacity, keep_ws_cap = e->wide_ws_capacity;
   int *keep = e->d_owner;
-  e->d_owner = nullptr;
+  void *keep_ws = e->d_wide_ws;
+  e->d_owner = nullptr; e->d_wide_ws = nullptr;
   free_pairs(e);
   e->d_owner = keep; e->owner_capacity = keep_owner;
+  e->d_wide_ws = keep_ws; e->wide_ws_capacity = keep_ws_cap;
   PHOVO_HIP_CHECK(hipMalloc(&e->d_src, sizeof(int) * (size_t)n_pairs));
   PHOVO_HIP_CHECK(hipMalloc(&e->d_tgt, sizeof(int) * (size_t)n_pairs));
   PHOVO_HIP_CHECK(hipMalloc(&e->d_states, sizeof(double) * 6 * (size_t)n_pairs));
@@ -443,6 +461,20 @@ int phovo_engine_set_depth_range(phovo_engine *e, double min_depth, double max_d
   return PHOVO_OK;
 }
 
+int phovo_engine_set_wide_policy(phovo_engine *e, int policy)
+{
+  if (!e) return fail(PHOVO_E_INVALID_ARGUMENT, "set_wide_policy: null");
+  if (policy < -1 || policy > 1) return fail(PHOVO_E_INVALID_ARGUMENT, "set_wide_policy: policy must be -1, 0 or 1");
+  e->wide_policy = policy;
+  return PHOVO_OK;
+}
+
+int phovo_engine_level_uses_wide(const phovo_engine *e, int level, int n_pairs)
+{
+  if (!e || level < 0 || level >= e->cfg.num_levels || e->n_frames == 0) return 0;
+  return use_wide_level(e, n_pairs, e->levels[level].n) && !(e->ext.huber_delta[level] > 0.0) ? 1 : 0;
+}
+
 int phovo_engine_set_build_all_levels(phovo_engine *e, int on)
 {
   if (!e) return fail(PHOVO_E_INVALID_ARGUMENT, "set_build_all_levels: null");
@@ -707,14 +739,19 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
   if (st != PHOVO_OK) return st;
 
   // every active level must be launchable before anything is enqueued
-  size_t owner_need = 0;
+  size_t owner_need = 0, wide_need = 0;
   for (int l = 0; l < e->cfg.num_levels; l++) {
     if (e->cfg.max_num_iterations[l] <= 0) continue;
     const LevelPool &lv = e->levels[l];
     if (!lv.stored) return fail(PHOVO_E_NOT_READY, "align: an active level is not resident");
     if (e->ext.sampling == PHOVO_SAMPLING_BILINEAR) continue;       // no owner map, no LDS limit
-    if (!lv.plan_ok) return fail(PHOVO_E_SHAPE, "align: pyramid level too large for the device path (in-bounds mask exceeds LDS)");
-    if (!lv.plan.owner_in_lds) {
+    const bool wide = use_wide_level(e, n_pairs, lv.n) && !(e->ext.huber_delta[l] > 0.0);
+    if (wide) {
+      const size_t ws = gn_wide_workspace_bytes(lv.n, n_pairs);
+      if (ws > wide_need) wide_need = ws;
+    }
+    if (!wide && !lv.plan_ok) return fail(PHOVO_E_SHAPE, "align: pyramid level too large for the device path (in-bounds mask exceeds LDS)");
+    if (wide || !lv.plan.owner_in_lds) {
       const size_t need = (size_t)n_pairs * (size_t)lv.n;
       if (need > owner_need) owner_need = need;
     }
@@ -727,6 +764,12 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
     PHOVO_HIP_CHECK(fill_i32(e->d_owner, owner_need, -1, e->stream));
   }
 
+  if (wide_need > e->wide_ws_capacity) {
+    if (e->d_wide_ws) { PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream)); (void)hipFree(e->d_wide_ws); e->d_wide_ws = nullptr; e->wide_ws_capacity = 0; }
+    PHOVO_HIP_CHECK(hipMalloc(&e->d_wide_ws, wide_need));
+    e->wide_ws_capacity = wide_need;
+  }
+  if (wide_need) e->h_wide_done.resize((size_t)n_pairs * 4);
   PHOVO_HIP_CHECK(hipMemcpyAsync(e->d_src, source_frames, sizeof(int) * (size_t)n_pairs, hipMemcpyHostToDevice, e->stream));
   PHOVO_HIP_CHECK(hipMemcpyAsync(e->d_tgt, target_frames, sizeof(int) * (size_t)n_pairs, hipMemcpyHostToDevice, e->stream));
   if (init_states)                                                                   // SetInitialStateVector  :494
@@ -759,6 +802,8 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
     PHOVO_HIP_CHECK(hipEventRecord(e->ev_start[l], e->stream));
     if (e->ext.sampling == PHOVO_SAMPLING_BILINEAR)
       PHOVO_HIP_CHECK(gn_launch_level_bilinear(a, e->ext.plane_storage, e->ext.jacobian_corrected != 0, n_pairs, e->stream));
+    else if (use_wide_level(e, n_pairs, lv.n) && !(e->ext.huber_delta[l] > 0.0))
+      PHOVO_HIP_CHECK(gn_run_level_wide(a, n_pairs, e->d_wide_ws, e->h_wide_done.data(), e->stream));
     else
       PHOVO_HIP_CHECK(gn_launch_level(a, lv.plan, e->ext.plane_storage, n_pairs, e->stream));
     PHOVO_HIP_CHECK(hipEventRecord(e->ev_stop[l], e->stream));

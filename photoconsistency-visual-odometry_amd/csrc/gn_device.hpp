@@ -1,0 +1,272 @@
+// Device-side building blocks shared by the Gauss-Newton kernels (gn_kernels.hip, gn_wide_kernels.hip):
+// pose constants, wave / workgroup reductions, the 6x6 solve, typed plane loads.  Everything is
+// __forceinline__ in an anonymous namespace: each translation unit gets its own copy.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include "phovo_internal.hpp"
+
+namespace phovo_hip {
+
+namespace {
+
+constexpr int WAVE = 64;
+constexpr int NRED = 32;     // padded for the butterfly
+
+// Indices into the pose-constant block in LDS.
+enum {
+  C_X = 0, C_Y, C_Z, C_R01, C_R02, C_R11, C_R12,
+  C_T1, C_T2, C_T3, C_T4, C_T5, C_T6, C_T8, C_T11, C_T14, C_T15,
+  C_T16, C_T17, C_T24, C_CY, C_SY, C_COUNT
+};
+
+// Control words in LDS.
+enum { CTL_DONE = 0, CTL_FLAGS = 1, CTL_COUNT = 4 };
+
+__device__ __forceinline__ double uniform_f64(double v)
+{
+  // The value is identical in every lane: move it to scalar registers so that the per-pixel
+  // math reads it as an SGPR operand instead of burning two VGPRs per constant.
+  int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+// Pose constants from the state: Rt (:219-241) and temp1..temp24 (:243-266), written with the
+// reference's association.  temp7 = -temp6, temp9 = -temp8, temp21 = -temp5, temp22 = temp2,
+// temp23 = temp1 hold exactly in IEEE arithmetic and are not stored; Rt(0,0) = temp15,
+// Rt(1,0) = temp14, Rt(2,0) = -temp3, Rt(2,1) = temp1, Rt(2,2) = temp2 likewise.  temp10, temp12, temp13 are
+// temp1, temp2, temp3 times cos(yaw) and temp18, temp19, temp20 the same times sin(yaw): the kernel applies
+// those two factors to the sum instead (see pass 2), so only cos(yaw) and sin(yaw) are stored.
+__device__ __forceinline__ void write_pose_constants(double x, double y, double z, double yaw, double pitch,
+                                                     double roll, double *cst, int lane)
+{
+  // Lanes 0, 1, 2 take yaw, pitch, roll: ONE sincos issue instead of three dependent ones; the six
+  // results are then broadcast (the whole wave executes this with a wave-uniform state).
+  const double ang = (lane == 1) ? pitch : ((lane == 2) ? roll : yaw);
+  double sn, cs;
+  sincos(ang, &sn, &cs);
+  const double sy = __shfl(sn, 0, WAVE), cy = __shfl(cs, 0, WAVE);
+  const double sp = __shfl(sn, 1, WAVE), cp = __shfl(cs, 1, WAVE);
+  const double sr = __shfl(sn, 2, WAVE), cr = __shfl(cs, 2, WAVE);
+  if (lane != 0) return;
+  cst[C_X] = x; cst[C_Y] = y; cst[C_Z] = z;
+  cst[C_R01] = cy * sp * sr - sy * cr;
+  cst[C_R02] = cy * sp * cr + sy * sr;
+  cst[C_R11] = sy * sp * sr + cy * cr;
+  cst[C_R12] = sy * sp * cr - cy * sr;
+  cst[C_T1] = cp * sr;
+  cst[C_T2] = cp * cr;
+  cst[C_T3] = sp;
+  cst[C_T4] = sr * sy + sp * cr * cy;
+  cst[C_T5] = sp * sr * cy - cr * sy;
+  cst[C_T6] = sp * sr * sy + cr * cy;
+  cst[C_T8] = sr * cy - sp * cr * sy;
+  cst[C_T11] = cp * cy + x;          // the reference's bug, kept (:253)
+  cst[C_T14] = cp * sy;
+  cst[C_T15] = cp * cy;
+  cst[C_T16] = sp * sr;
+  cst[C_T17] = sp * cr;
+  cst[C_T24] = cp;
+  cst[C_CY] = cy;
+  cst[C_SY] = sy;
+}
+
+// One butterfly stage of the transposed wave reduction: N values in, N/2 out.  The stage is issued in
+// groups of G exchanges with a scheduling fence between groups: left alone, the scheduler hoists all
+// N/2 select pairs in front of the shuffles and the live range grows by 4 VGPRs per exchange
+// (179 VGPRs and spills under the 128-register budget of a 1024-thread workgroup).
+template <int N, int G>
+__device__ __forceinline__ void reduce_stage(double (&v)[NRED], int lane, int dist)
+{
+  const bool up = (lane & dist) != 0;
+#pragma unroll
+  for (int base = 0; base < N / 2; base += G) {
+#pragma unroll
+    for (int i = base; i < base + G && i < N / 2; i++) {
+      const double send = up ? v[i] : v[i + N / 2];
+      const double keep = up ? v[i + N / 2] : v[i];
+      v[i] = keep + __shfl_xor(send, dist, WAVE);
+    }
+    if (N / 2 > G) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// The two widest butterfly stages without selects or LDS-crossbar traffic: gfx950's
+// v_permlane32_swap / v_permlane16_swap exchange the upper half (odd 16-lane rows) of one register with
+// the lower half (even rows) of another, so for the pair (v[i], v[i+N/2]) one swap per dword leaves
+//   newA = { own v[i] in the low lanes,  partner's v[i+N/2] in the high lanes }
+//   newB = { partner's v[i] in the low lanes,  own v[i+N/2] in the high lanes }
+// and newA + newB is exactly "keep + received" of reduce_stage with the same lane -> index map.
+template <int N, bool ROW16>
+__device__ __forceinline__ void reduce_stage_swap(double (&v)[NRED])
+{
+#pragma unroll
+  for (int i = 0; i < N / 2; i++) {
+    const unsigned alo = (unsigned)__double2loint(v[i]), ahi = (unsigned)__double2hiint(v[i]);
+    const unsigned blo = (unsigned)__double2loint(v[i + N / 2]), bhi = (unsigned)__double2hiint(v[i + N / 2]);
+    const auto lo = ROW16 ? __builtin_amdgcn_permlane16_swap(alo, blo, false, false)
+                          : __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+    const auto hi = ROW16 ? __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false)
+                          : __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    v[i] = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+  }
+}
+
+// 6x6 solve of the normal equations H x = g by an unpivoted LDL^T factorisation: H = J^T J is
+// symmetric positive semi-definite, for which LDL^T is backward stable, needs 6 reciprocals instead of
+// the 21 divisions + 15 row swaps of pivoted elimination and only the 21 upper-triangular sums.
+// (The reference forms H^-1 with Eigen's PartialPivLU, ...Analytic.h:540; both are accurate to
+// cond(H)*eps, far inside the 1e-5 pose bar -- tests/test_gpu_parity.py holds 1e-9.)
+// h is the upper triangle, row-major: h[idx(i,j)], i <= j.  Fully unrolled: every index is a
+// compile-time constant, nothing goes to scratch.
+__device__ __forceinline__ constexpr int tri(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }
+
+__device__ __forceinline__ void solve6_ldlt(const double (&h)[21], const double (&g)[6], double (&x)[6])
+{
+  double L[6][6];       // strictly lower part used
+  double Ld[6][6];      // L[i][k] * d[k]
+  double inv[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    double dj = h[tri(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; k++) dj = fma(-L[j][k], Ld[j][k], dj);
+    inv[j] = 1.0 / dj;
+#pragma unroll
+    for (int i = j + 1; i < 6; i++) {
+      double t = h[tri(j, i)];
+#pragma unroll
+      for (int k = 0; k < j; k++) t = fma(-L[i][k], Ld[j][k], t);
+      Ld[i][j] = t;
+      L[i][j] = t * inv[j];
+    }
+  }
+  double y[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    double t = g[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) t = fma(-L[i][k], y[k], t);
+    y[i] = t;
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    double t = y[i] * inv[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; k++) t = fma(-L[k][i], x[k], t);
+    x[i] = t;
+  }
+}
+
+// Plane loads go through buffer descriptors: the four planes of a chunk share ONE 32-bit byte offset
+// (8*k) in a VGPR while the bases sit in SGPRs, and a read past the plane returns 0 instead of needing
+// a branch (raw buffer, num_records = plane bytes).  Flat loads cost a 64-bit VGPR address per plane.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+template <typename T>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const unsigned char *p, int n)
+{
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(p), 0, n * (int)sizeof(T), 0x00020000);
+}
+// Element `idx` of a plane stored as T, widened to fp64 (all arithmetic stays fp64; narrower storage is the
+// opt-in extension of include/phovo_hip.h, PHOVO_STORAGE_*).  idx = -1 or past the plane reads 0.
+template <typename T>
+__device__ __forceinline__ double plane_load(__amdgpu_buffer_rsrc_t r, int idx);
+template <>
+__device__ __forceinline__ double plane_load<double>(__amdgpu_buffer_rsrc_t r, int idx)
+{
+  const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, idx * 8, 0, 0);
+  return __hiloint2double((int)v.y, (int)v.x);
+}
+template <>
+__device__ __forceinline__ double plane_load<float>(__amdgpu_buffer_rsrc_t r, int idx)
+{
+  return (double)__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, idx * 4, 0, 0));
+}
+template <>
+__device__ __forceinline__ double plane_load<__half>(__amdgpu_buffer_rsrc_t r, int idx)
+{
+  const unsigned short bits = __builtin_amdgcn_raw_buffer_load_b16(r, idx * 2, 0, 0);
+  return (double)__half2float(__ushort_as_half(bits));
+}
+
+// 1/x to within one ulp: v_rcp_f64 seeds two Newton steps.  The IEEE-exact division sequence is
+// 11 instructions, this is 5; the half-ulp it gives up is far below the fp64 noise floor of the sums
+// that follow (tests/test_gpu_parity.py holds the poses to 1e-9 against the oracle's exact divisions).
+__device__ __forceinline__ double fast_rcp(double x)
+{
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-x, r, 1.0);
+  return fma(r, e, r);
+}
+
+// Wave butterfly + cross-wave sum + solve + update + termination, as in gn_level_kernel's tail, for kernels
+// that keep their 27 sums in `acc`.  Returns after the closing barrier; the caller reads s_ctl[CTL_DONE].
+template <int NW>
+__device__ __forceinline__ void reduce_solve_update(double (&acc)[NRED], int lane, int wave, double *s_red,
+                                                    double *s_state, double *s_cst, int *s_ctl,
+                                                    double lambda, int max_iter, double min_grad_norm,
+                                                    int iteration, double &last_gnorm)
+{
+  reduce_stage_swap<32, false>(acc);
+  reduce_stage_swap<16, true>(acc);
+  reduce_stage<8, 4>(acc, lane, 8);
+  reduce_stage<4, 4>(acc, lane, 4);
+  reduce_stage<2, 4>(acc, lane, 2);
+  {
+    const double total = acc[0] + __shfl_xor(acc[0], 1, WAVE);
+    const int idx = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 +
+                    ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+    if ((lane & 1) == 0) s_red[wave * NRED + idx] = total;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    double v = 0.0;
+    {
+      const int j = lane & (NRED - 1);
+      const int w0 = (lane >> 5) * (NW / 2);
+#pragma unroll
+      for (int w2 = 0; w2 < NW / 2; w2++) v += s_red[(w0 + w2) * NRED + j];
+      v += __shfl_xor(v, 32, WAVE);
+    }
+    double h[21], g[6];
+#pragma unroll
+    for (int q = 0; q < 21; q++) h[q] = __shfl(v, q, WAVE);
+#pragma unroll
+    for (int i = 0; i < 6; i++) g[i] = __shfl(v, 21 + i, WAVE);
+    double step[6];
+    solve6_ldlt(h, g, step);
+    double st[6];
+    bool finite = true;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      st[i] = s_state[i] - lambda * step[i];                                            // :539
+      finite = finite && (fabs(st[i]) <= 1.79769313486231570815e308);
+    }
+    double gn2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) gn2 += g[i] * g[i];
+    const double gnorm = sqrt(gn2);                                                     // :380
+    bool done = false;
+    if (iteration + 1 >= max_iter) done = true;                                         // :383
+    else if (gnorm < min_grad_norm) done = true;                                        // :388
+    if (!finite) done = true;
+    if (!done) write_pose_constants(st[0], st[1], st[2], st[3], st[4], st[5], s_cst, lane);
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) s_state[i] = st[i];
+      s_ctl[CTL_DONE] = done ? 1 : 0;
+      if (!finite) s_ctl[CTL_FLAGS] |= (int)PHOVO_PAIR_NONFINITE;
+    }
+    last_gnorm = gnorm;
+  }
+  __syncthreads();
+}
+
+}  // namespace
+
+}  // namespace phovo_hip

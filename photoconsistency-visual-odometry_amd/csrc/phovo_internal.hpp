@@ -51,6 +51,11 @@ hipError_t gn_launch_level(const GNLevelArgs &args, const GNLaunchPlan &plan, in
 // Extension (PHOVO_SAMPLING_BILINEAR): single-pass kernel, 256 threads, no owner map, any level size.
 hipError_t gn_launch_level_bilinear(const GNLevelArgs &args, int storage, bool corrected, int n_pairs,
                                     hipStream_t stream);
+// Wide form (gn_wide_kernels.hip): many workgroups per pair, three launches per iteration; for a handful of
+// pairs on large levels.  fp64 planes, reference semantics only.
+size_t gn_wide_workspace_bytes(int n, int n_pairs);
+hipError_t gn_run_level_wide(const GNLevelArgs &args, int n_pairs, void *workspace, int *h_done_scratch,
+                             hipStream_t stream);
 hipError_t gn_prepare_kernels();   // raises the dynamic-LDS limit of every instantiation
 
 // Pyramid producers (SetSourceFrame / SetTargetFrame, ...Analytic.h:466-491), batched over `frames`

@@ -184,6 +184,13 @@ class AlignmentEngine:
     def set_build_all_levels(self, on):
         check(self._lib.phovo_engine_set_build_all_levels(self._h, int(bool(on))), "phovo_engine_set_build_all_levels")
 
+    def set_wide_policy(self, policy):
+        """0 automatic, 1 wide form wherever possible, -1 persistent form only."""
+        check(self._lib.phovo_engine_set_wide_policy(self._h, int(policy)), "phovo_engine_set_wide_policy")
+
+    def level_uses_wide(self, level, n_pairs):
+        return bool(self._lib.phovo_engine_level_uses_wide(self._h, int(level), int(n_pairs)))
+
     def reserve_frames(self, n_frames, width, height):
         check(self._lib.phovo_engine_reserve_frames(self._h, int(n_frames), int(width), int(height)),
               "phovo_engine_reserve_frames")

@@ -433,3 +433,41 @@ def test_every_kernel_variant_matches_oracle(size, expect):
     assert np.array_equal(s[0], s[1]) and np.array_equal(s[0], s[2])
     g_last = np.linalg.norm(etr[-1]["gradient"])
     assert abs(reps[0].gradient_norm - g_last) <= 1e-9 * max(1.0, g_last)
+
+
+@pytest.mark.parametrize("size,levels,max_iter,min_grad", [
+    ((640, 480), 1, [12], [300.0]),                       # config_only_level_0: 300 tiles of 1024 pixels
+    ((640, 480), 4, [0, 0, 20, 50], [300.0] * 4),         # forced: small levels, uneven last tile (19200 = 18.75 tiles)
+    ((200, 152), 2, [6, 9], [0.0, 0.0]),                  # odd sizes, partial last chunk
+])
+def test_wide_form_equals_persistent_form_and_oracle(size, levels, max_iter, min_grad):
+    """The many-workgroups-per-pair form (three launches per iteration) against the one-workgroup-per-pair form
+    and the oracle: identical iteration counts, poses within the bar, pairs that stop at different iterations."""
+    w, h = size
+    pairs = [synthetic.make_pair(40 + i, w, h, holes=0.02, trans=0.004 * (i + 1), rot=0.002 * (i + 1)) for i in range(3)]
+    ncfg, ocfg = _cfgs(levels, max_iter, min_grad)
+    exp = [oracle.align_frames(ocfg, p["K"], p["gray0"], p["depth0"], p["gray1"]) for p in pairs]
+    with odometry.AlignmentEngine() as eng:
+        eng.set_config(ncfg)
+        eng.set_intrinsic_matrix(pairs[0]["K"])
+        eng.reserve_frames(6, w, h)
+        for i, p in enumerate(pairs):
+            eng.upload_frame(2 * i, p["gray0"], p["depth0"])
+            eng.upload_frame(2 * i + 1, p["gray1"], p["depth1"])
+        src, tgt = [0, 2, 4], [1, 3, 5]
+        eng.set_wide_policy(-1)
+        assert not any(eng.level_uses_wide(l, 3) for l in range(levels))
+        sp, rp = eng.align_pairs(src, tgt, want_reports=True)
+        eng.set_wide_policy(1)
+        assert all(eng.level_uses_wide(l, 3) for l in range(levels))
+        sw, rw = eng.align_pairs(src, tgt, want_reports=True)
+        sw2 = eng.align_pairs(src, tgt)                                   # owner map clean again, deterministic
+        eng.set_wide_policy(0)
+        auto = [eng.level_uses_wide(l, 3) for l in range(levels)]
+        assert auto == [eng.level_size(l)[0] * eng.level_size(l)[1] >= 16384 for l in range(levels)]
+        assert not eng.level_uses_wide(0, 64)                              # many pairs: persistent form
+    for i, (es, eits) in enumerate(exp):
+        assert list(rp[i].iterations[:levels]) == eits and list(rw[i].iterations[:levels]) == eits
+        assert se3.state_distance(sw[i], es) < POSE_TOL and se3.state_distance(sp[i], es) < POSE_TOL
+        assert abs(rw[i].gradient_norm - rp[i].gradient_norm) <= 1e-9 * max(1.0, rp[i].gradient_norm)
+    assert np.array_equal(sw, sw2)
