@@ -7,7 +7,7 @@
 // 256-thread workgroup, and an iteration is three launches on one stream:
 //   k_wide_pass1   warp every source pixel, atomicMax into the owner map in HBM (...Analytic.h:279-303,358)
 //   k_wide_pass2   residual / Jacobian rows / 27 partial sums per tile (:308-356, :538-540)
-//   k_wide_solve   one wave per pair: fixed-order sum over tiles, LDL^T, state update, termination (:539-549)
+//   k_wide_solve   one workgroup per pair: fixed-order sum over tiles, LDL^T, state update, termination (:539-549)
 // There is no in-kernel grid barrier: the kernel boundary is the synchronisation, so nothing can hang; the host
 // looks at the per-pair "done" words every few iterations.  Same arithmetic as the persistent kernel (same helper
 // functions), same reference semantics, fp64 planes only (the narrow storages and Huber weights are served by
@@ -183,15 +183,32 @@ __global__ __launch_bounds__(WT) void k_wide_pass2(const GNLevelArgs A, const do
   }
 }
 
-__global__ __launch_bounds__(WAVE) void k_wide_solve(const GNLevelArgs A, double *g_cst, int *g_ctl,
-                                                     const double *g_part, int tiles)
+constexpr int SOLVE_T = 256;            // threads of the solve kernel: 8 interleaved tile subsets x 32 values
+
+__global__ __launch_bounds__(SOLVE_T) void k_wide_solve(const GNLevelArgs A, double *g_cst, int *g_ctl,
+                                                        const double *g_part, int tiles)
 {
-  const int pair = blockIdx.x, lane = threadIdx.x;
+  const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & (WAVE - 1);
   int *ctl = g_ctl + pair * W_COUNT;
   if (ctl[W_DONE]) return;
+  // Tile sums in a fixed order without a 300-deep dependent chain: thread (s, j) adds tiles s, s+8, s+16, ...
+  // of value j (independent loads, pipelined), then the 8 subset sums are added in subset order.
+  __shared__ double s_part[(SOLVE_T / NRED) * NRED];
+  {
+    const int j = tid & (NRED - 1), sub = tid / NRED;
+    const double *base = g_part + (size_t)pair * tiles * NRED + j;
+    double v0 = 0.0;
+#pragma unroll 4
+    for (int t = sub; t < tiles; t += SOLVE_T / NRED) v0 += base[(size_t)t * NRED];
+    s_part[sub * NRED + j] = v0;
+  }
+  __syncthreads();
+  if (tid >= WAVE) return;
   double v = 0.0;
-  if (lane < NRED)
-    for (int t = 0; t < tiles; t++) v += g_part[((size_t)pair * tiles + t) * NRED + lane];   // fixed order
+  if (lane < NRED) {
+#pragma unroll
+    for (int sub = 0; sub < SOLVE_T / NRED; sub++) v += s_part[sub * NRED + lane];
+  }
   double h[21], g[6];
 #pragma unroll
   for (int q = 0; q < 21; q++) h[q] = __shfl(v, q, WAVE);
@@ -260,7 +277,7 @@ hipError_t gn_run_level_wide(const GNLevelArgs &a, int n_pairs, void *workspace,
   for (int it = 0; it < a.max_iter; it++) {
     hipLaunchKernelGGL(k_wide_pass1, grid, dim3(WT), 0, stream, a, g_cst, g_ctl, g_mask);
     hipLaunchKernelGGL(k_wide_pass2, grid, dim3(WT), 0, stream, a, g_cst, g_ctl, g_mask, g_part, tiles);
-    hipLaunchKernelGGL(k_wide_solve, dim3(n_pairs), dim3(WAVE), 0, stream, a, g_cst, g_ctl, g_part, tiles);
+    hipLaunchKernelGGL(k_wide_solve, dim3(n_pairs), dim3(SOLVE_T), 0, stream, a, g_cst, g_ctl, g_part, tiles);
     if ((it + 1) % check_every == 0 && it + 1 < a.max_iter) {
       hipError_t e = hipMemcpyAsync(h_done_scratch, g_ctl, sizeof(int) * W_COUNT * (size_t)n_pairs,
                                     hipMemcpyDeviceToHost, stream);
