@@ -227,7 +227,9 @@ int phovo_engine_align_pairs(phovo_engine *e, int n_pairs,
                              const int *source_frames, const int *target_frames,
                              const double *init_states, double *out_states,
                              phovo_pair_report *reports);
-/* Split form: enqueue on the engine's stream without waiting, then wait, then fetch. */
+/* Split form: enqueue on the engine's stream without waiting, then wait, then fetch.  The argument arrays are
+ * copied before the call returns.  (Levels that run in the wide form synchronise the stream every 8 iterations
+ * to look at the "done" words, so for them the call returns when the level has finished.) */
 int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs,
                                const int *source_frames, const int *target_frames,
                                const double *init_states);

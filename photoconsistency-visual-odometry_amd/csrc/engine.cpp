@@ -79,6 +79,8 @@ struct phovo_engine {
   void *d_wide_ws = nullptr;                   // workspace of the wide (many-workgroups-per-pair) level form
   size_t wide_ws_capacity = 0;
   std::vector<int> h_wide_done;
+  std::vector<int> h_src, h_tgt;               // host copies of the last pair list / initial states (see enqueue)
+  std::vector<double> h_init;
   int wide_policy = 0;                         // 0 auto, 1 always (where possible), -1 never
   int last_pairs = 0;
 };
@@ -770,11 +772,18 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
     e->wide_ws_capacity = wide_need;
   }
   if (wide_need) e->h_wide_done.resize((size_t)n_pairs * 4);
-  PHOVO_HIP_CHECK(hipMemcpyAsync(e->d_src, source_frames, sizeof(int) * (size_t)n_pairs, hipMemcpyHostToDevice, e->stream));
-  PHOVO_HIP_CHECK(hipMemcpyAsync(e->d_tgt, target_frames, sizeof(int) * (size_t)n_pairs, hipMemcpyHostToDevice, e->stream));
-  if (init_states)                                                                   // SetInitialStateVector  :494
-    PHOVO_HIP_CHECK(hipMemcpyAsync(e->d_states, init_states, sizeof(double) * 6 * (size_t)n_pairs, hipMemcpyHostToDevice, e->stream));
-  else
+  // The caller may reuse its arrays as soon as this returns and the copies below are asynchronous: keep
+  // engine-owned copies alive until the next enqueue (the previous ones are no longer in flight: the stream
+  // is in order and their copies precede everything enqueued since).
+  PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
+  e->h_src.assign(source_frames, source_frames + n_pairs);
+  e->h_tgt.assign(target_frames, target_frames + n_pairs);
+  PHOVO_HIP_CHECK(hipMemcpyAsync(e->d_src, e->h_src.data(), sizeof(int) * (size_t)n_pairs, hipMemcpyHostToDevice, e->stream));
+  PHOVO_HIP_CHECK(hipMemcpyAsync(e->d_tgt, e->h_tgt.data(), sizeof(int) * (size_t)n_pairs, hipMemcpyHostToDevice, e->stream));
+  if (init_states) {                                                                 // SetInitialStateVector  :494
+    e->h_init.assign(init_states, init_states + 6 * (size_t)n_pairs);
+    PHOVO_HIP_CHECK(hipMemcpyAsync(e->d_states, e->h_init.data(), sizeof(double) * 6 * (size_t)n_pairs, hipMemcpyHostToDevice, e->stream));
+  } else
     PHOVO_HIP_CHECK(hipMemsetAsync(e->d_states, 0, sizeof(double) * 6 * (size_t)n_pairs, e->stream));
   PHOVO_HIP_CHECK(hipMemsetAsync(e->d_reports, 0, sizeof(phovo_pair_report) * (size_t)n_pairs, e->stream));
 
