@@ -186,10 +186,13 @@ def main():
     # HBM bytes per launch of the dominant kernel from the PMC counters: collected in separate rocprofv3 --pmc
     # passes of this same command and calibrated (profiles/README.md); cannot be measured from inside the run.
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    storage_types = {"f64": "double, double>", "f32": "float, float>", "f16": "__half, float>"}
+    plain_mode = args.huber == 0.0 and not args.bilinear      # the counters were collected on the reference path
     if os.path.exists(pmc):
         try:
             for kd in json.load(open(pmc)).get("kernels", []):
-                if kd.get("threads") == dom["threads"] and kd.get("pairs") == n_local:
+                if (kd.get("threads") == dom["threads"] and kd.get("pairs") == n_local and plain_mode
+                        and storage_types[args.storage] in kd.get("kernel", "")):
                     roofline["traffic"] = kd["hbm_bytes_per_launch"]
                     roofline["traffic_over_algorithmic"] = kd["hbm_bytes_per_launch"] / dom["algorithmic_bytes"]
                     roofline["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, calibrated)"

@@ -76,6 +76,8 @@ struct phovo_engine {
   phovo_pair_report *d_reports = nullptr;
   int *d_owner = nullptr;
   size_t owner_capacity = 0;
+  int *d_work_counters = nullptr;              // [PHOVO_MAX_LEVELS] pair counters of the persistent kernels' work queues
+  int cu_count = 256;
   void *d_wide_ws = nullptr;                   // workspace of the wide (many-workgroups-per-pair) level form
   size_t wide_ws_capacity = 0;
   std::vector<int> h_wide_done;
@@ -356,6 +358,11 @@ int phovo_engine_create(int device, phovo_engine **out)
     }
   }
   if (he == hipSuccess) he = gn_prepare_kernels();
+  if (he == hipSuccess) he = hipMalloc(&e->d_work_counters, sizeof(int) * PHOVO_MAX_LEVELS);
+  if (he == hipSuccess) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) e->cu_count = cus;
+  }
   if (he != hipSuccess) {
     phovo_engine_destroy(e);
     return fail(PHOVO_E_HIP, std::string("engine setup: ") + hipGetErrorString(he));
@@ -371,6 +378,7 @@ int phovo_engine_destroy(phovo_engine *e)
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   free_pool(e);
   free_pairs(e);
+  if (e->d_work_counters) (void)hipFree(e->d_work_counters);
   for (int l = 0; l < PHOVO_MAX_LEVELS; l++) {
     if (e->ev_start[l]) (void)hipEventDestroy(e->ev_start[l]);
     if (e->ev_stop[l]) (void)hipEventDestroy(e->ev_stop[l]);
@@ -808,13 +816,16 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
     a.src = e->d_src; a.tgt = e->d_tgt;
     a.states = e->d_states; a.reports = e->d_reports;
     a.g_owner = e->d_owner;
+    a.n_pairs = n_pairs;
+    a.work_counter = e->d_work_counters + l;
+    PHOVO_HIP_CHECK(hipMemsetAsync(e->d_work_counters + l, 0, sizeof(int), e->stream));
     PHOVO_HIP_CHECK(hipEventRecord(e->ev_start[l], e->stream));
     if (e->ext.sampling == PHOVO_SAMPLING_BILINEAR)
-      PHOVO_HIP_CHECK(gn_launch_level_bilinear(a, e->ext.plane_storage, e->ext.jacobian_corrected != 0, n_pairs, e->stream));
+      PHOVO_HIP_CHECK(gn_launch_level_bilinear(a, e->ext.plane_storage, e->ext.jacobian_corrected != 0, e->cu_count, e->stream));
     else if (use_wide_level(e, n_pairs, lv.n) && !(e->ext.huber_delta[l] > 0.0))
       PHOVO_HIP_CHECK(gn_run_level_wide(a, n_pairs, e->d_wide_ws, e->h_wide_done.data(), e->stream));
     else
-      PHOVO_HIP_CHECK(gn_launch_level(a, lv.plan, e->ext.plane_storage, n_pairs, e->stream));
+      PHOVO_HIP_CHECK(gn_launch_level(a, lv.plan, e->ext.plane_storage, e->cu_count, e->stream));
     PHOVO_HIP_CHECK(hipEventRecord(e->ev_stop[l], e->stream));
     e->level_launched[l] = true;
   }

@@ -23,7 +23,7 @@ enum {
 };
 
 // Control words in LDS.
-enum { CTL_DONE = 0, CTL_FLAGS = 1, CTL_COUNT = 4 };
+enum { CTL_DONE = 0, CTL_FLAGS = 1, CTL_PAIR = 2, CTL_COUNT = 4 };
 
 __device__ __forceinline__ double uniform_f64(double v)
 {

@@ -66,8 +66,19 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
   // wave-uniform by construction; saying so lets the chunk loops run on the scalar unit (s_cmp / s_cbranch)
   // instead of exec-masked vector compares
   const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
-  const int pair = blockIdx.x;
   const int n = A.n, W = A.w, H = A.h;
+  // Work queue: the grid has as many workgroups as fit the chip; each draws pair after pair from an atomic counter.
+  // Pairs stop after data-dependent iteration counts and the hardware deals blocks to the 8 XCDs round-robin, so a
+  // one-block-per-pair grid leaves whole XCDs idle while another one still works through its long pairs.
+  // Thread 0 draws the next index in the same block that writes the finished pair back, so that the only thing between
+  // the iteration loop and the barrier at the head of the work loop is one if-block (two adjacent `if (tid == 0)`
+  // blocks, one either side of the back edge, were threaded together by the compiler into a loop that reached that
+  // barrier with thread 0 parked: a hang).
+  if (tid == 0) s_ctl[CTL_PAIR] = atomicAdd(A.work_counter, 1);
+  for (;;) {
+  __syncthreads();
+  const int pair = __builtin_amdgcn_readfirstlane(s_ctl[CTL_PAIR]);
+  if (pair >= A.n_pairs) break;           // uniform: every wave of the workgroup leaves together
 
   const unsigned char *src_frame = A.planes + (size_t)A.src[pair] * A.frame_bytes;
   const unsigned char *tgt_frame = A.planes + (size_t)A.tgt[pair] * A.frame_bytes;
@@ -361,7 +372,9 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
       for (int j = 0; j < 5; j++) A.reports[pair].iterations[8 + j] = (int)(st_sum[j] / (unsigned long long)iteration);
 #endif
     }
+    s_ctl[CTL_PAIR] = atomicAdd(A.work_counter, 1);
   }
+  }   // next pair
 }
 
 // EXTENSION, NOT IN THE REFERENCE'S ANALYTIC PATH (PHOVO_SAMPLING_BILINEAR): forward-additive alignment with
@@ -386,8 +399,12 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel_bilinear(const GNLevel
   const int tid = threadIdx.x;
   const int lane = tid & (WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
-  const int pair = blockIdx.x;
   const int n = A.n, W = A.w, H = A.h;
+  if (tid == 0) s_ctl[CTL_PAIR] = atomicAdd(A.work_counter, 1);
+  for (;;) {                                // work queue, as in gn_level_kernel
+  __syncthreads();
+  const int pair = __builtin_amdgcn_readfirstlane(s_ctl[CTL_PAIR]);
+  if (pair >= A.n_pairs) break;
   const unsigned char *src_frame = A.planes + (size_t)A.src[pair] * A.frame_bytes;
   const unsigned char *tgt_frame = A.planes + (size_t)A.tgt[pair] * A.frame_bytes;
   const __amdgpu_buffer_rsrc_t rI0 = plane_rsrc<TI>(src_frame + A.plane_off[PLANE_I], n);
@@ -511,7 +528,9 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel_bilinear(const GNLevel
       A.reports[pair].gradient_norm = last_gnorm;
       A.reports[pair].flags |= (uint32_t)s_ctl[CTL_FLAGS];
     }
+    s_ctl[CTL_PAIR] = atomicAdd(A.work_counter, 1);
   }
+  }   // next pair
 }
 
 constexpr size_t LDS_LIMIT = 160 * 1024;   // MI355X: 160 KiB per CU, one workgroup may take all of it
@@ -546,7 +565,7 @@ bool gn_plan_level(int n, GNLaunchPlan *plan)
   const size_t owner = sizeof(int) * (size_t)((n + 1) & ~1);
   const size_t src = sizeof(double) * (size_t)n;
   if (n <= 2048) {
-    plan->variant = V_TINY; plan->threads = 256; plan->owner_in_lds = true; plan->source_in_lds = true;
+    plan->variant = V_TINY; plan->threads = 256; plan->wgs_per_cu = 4; plan->owner_in_lds = true; plan->source_in_lds = true;
     plan->lds_bytes = (int)(lds_fixed_bytes(256) + owner + src);
     return true;
   }
@@ -556,7 +575,7 @@ bool gn_plan_level(int n, GNLaunchPlan *plan)
   // PHOVO_GN_NO_QUAD=1 is a tuning aid for tools/ only.
   static const bool no_quad = std::getenv("PHOVO_GN_NO_QUAD") != nullptr;
   if (!no_quad && n_chunks <= 64 * 4 && f256 + owner <= LDS_LIMIT / 4) {
-    plan->variant = V_QUAD; plan->threads = 256; plan->owner_in_lds = true; plan->source_in_lds = false;
+    plan->variant = V_QUAD; plan->threads = 256; plan->wgs_per_cu = 4; plan->owner_in_lds = true; plan->source_in_lds = false;
     plan->lds_bytes = (int)(f256 + owner);
     return true;
   }
@@ -564,18 +583,18 @@ bool gn_plan_level(int n, GNLaunchPlan *plan)
   const bool reg512 = n_chunks <= 64 * 8, reg1024 = n_chunks <= 64 * 16;
   static const bool force_wide = std::getenv("PHOVO_GN_FORCE_WIDE") != nullptr;     // tuning aid
   if (!force_wide && reg512 && f512 + owner <= LDS_HALF) {
-    plan->variant = V_MID; plan->threads = 512; plan->owner_in_lds = true; plan->source_in_lds = false;
+    plan->variant = V_MID; plan->threads = 512; plan->wgs_per_cu = 2; plan->owner_in_lds = true; plan->source_in_lds = false;
     plan->lds_bytes = (int)(f512 + owner);
     return true;
   }
   if (reg1024 && f1024 + owner <= LDS_LIMIT) {
-    plan->variant = V_WIDE; plan->threads = 1024; plan->owner_in_lds = true; plan->source_in_lds = false;
+    plan->variant = V_WIDE; plan->threads = 1024; plan->wgs_per_cu = 1; plan->owner_in_lds = true; plan->source_in_lds = false;
     plan->lds_bytes = (int)(f1024 + owner);
     return true;
   }
   const size_t mask = sizeof(unsigned long long) * n_chunks;
   if (f1024 + mask > LDS_LIMIT) return false;
-  plan->variant = V_HUGE; plan->threads = 1024; plan->owner_in_lds = false; plan->source_in_lds = false;
+  plan->variant = V_HUGE; plan->threads = 1024; plan->wgs_per_cu = 1; plan->owner_in_lds = false; plan->source_in_lds = false;
   plan->lds_bytes = (int)(f1024 + mask);
   return true;
 }
@@ -598,10 +617,10 @@ hipError_t prepare_storage()
 }
 
 template <typename TI, typename TD>
-hipError_t launch_storage(const GNLevelArgs &a, const GNLaunchPlan &plan, int n_pairs, hipStream_t stream)
+hipError_t launch_storage(const GNLevelArgs &a, const GNLaunchPlan &plan, int n_blocks, hipStream_t stream)
 {
   const size_t lds = (size_t)plan.lds_bytes;
-  const dim3 grid((unsigned)n_pairs), block((unsigned)plan.threads);
+  const dim3 grid((unsigned)n_blocks), block((unsigned)plan.threads);
   switch (plan.variant) {
     case V_TINY:  hipLaunchKernelGGL(PHOVO_KERNEL_TINY(TI, TD), grid, block, lds, stream, a); break;
     case V_MID:   hipLaunchKernelGGL(PHOVO_KERNEL_MID(TI, TD), grid, block, lds, stream, a); break;
@@ -614,19 +633,20 @@ hipError_t launch_storage(const GNLevelArgs &a, const GNLaunchPlan &plan, int n_
 }
 
 template <typename TI, typename TD>
-hipError_t launch_bilinear_storage(const GNLevelArgs &a, bool corrected, int n_pairs, hipStream_t stream)
+hipError_t launch_bilinear_storage(const GNLevelArgs &a, bool corrected, int n_blocks, hipStream_t stream)
 {
-  const dim3 grid((unsigned)n_pairs), block(256);
+  const dim3 grid((unsigned)n_blocks), block(256);
   const size_t lds = lds_fixed_bytes(256);
   if (corrected) hipLaunchKernelGGL((gn_level_kernel_bilinear<256, 4, TI, TD, true>), grid, block, lds, stream, a);
   else hipLaunchKernelGGL((gn_level_kernel_bilinear<256, 4, TI, TD, false>), grid, block, lds, stream, a);
   return hipGetLastError();
 }
 
-hipError_t gn_launch_level_bilinear(const GNLevelArgs &a, int storage, bool corrected, int n_pairs,
+hipError_t gn_launch_level_bilinear(const GNLevelArgs &a, int storage, bool corrected, int cu_count,
                                     hipStream_t stream)
 {
-  if (n_pairs <= 0) return hipSuccess;
+  if (a.n_pairs <= 0) return hipSuccess;
+  const int n_pairs = a.n_pairs < cu_count * 4 ? a.n_pairs : cu_count * 4;     // persistent grid: 4 workgroups per CU
   switch (storage) {
     case PHOVO_STORAGE_F64: return launch_bilinear_storage<double, double>(a, corrected, n_pairs, stream);
     case PHOVO_STORAGE_F32: return launch_bilinear_storage<float, float>(a, corrected, n_pairs, stream);
@@ -643,10 +663,12 @@ hipError_t gn_prepare_kernels()
   return prepare_storage<__half, float>();
 }
 
-hipError_t gn_launch_level(const GNLevelArgs &a, const GNLaunchPlan &plan, int storage, int n_pairs,
+hipError_t gn_launch_level(const GNLevelArgs &a, const GNLaunchPlan &plan, int storage, int cu_count,
                            hipStream_t stream)
 {
-  if (n_pairs <= 0) return hipSuccess;
+  if (a.n_pairs <= 0) return hipSuccess;
+  const int slots = cu_count * plan.wgs_per_cu;                                // what the chip holds at once
+  const int n_pairs = a.n_pairs < slots ? a.n_pairs : slots;                   // persistent grid size
   switch (storage) {
     case PHOVO_STORAGE_F64: return launch_storage<double, double>(a, plan, n_pairs, stream);
     case PHOVO_STORAGE_F32: return launch_storage<float, float>(a, plan, n_pairs, stream);

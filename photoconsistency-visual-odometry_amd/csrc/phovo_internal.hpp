@@ -33,11 +33,14 @@ struct GNLevelArgs {
   double *states;           // [pairs][6] in: initial / previous level, out: updated
   phovo_pair_report *reports;   // [pairs]
   int *g_owner;             // [pairs][n] owner map in global memory (only when it does not fit LDS)
+  int n_pairs;              // pairs of this launch
+  int *work_counter;        // zeroed before the launch: workgroups draw pair indices from it (work queue)
 };
 
 struct GNLaunchPlan {
   int variant;              // which instantiation of the level kernel (gn_kernels.hip)
   int threads;              // workgroup size
+  int wgs_per_cu;           // workgroups of this geometry that fit one CU (sizes the persistent grid)
   int lds_bytes;            // dynamic LDS
   bool owner_in_lds;
   bool source_in_lds;
@@ -46,10 +49,11 @@ struct GNLaunchPlan {
 // Chooses the launch geometry for a level of n pixels.  Returns false if the level cannot be
 // handled (inbound-mask does not fit LDS).
 bool gn_plan_level(int n, GNLaunchPlan *plan);
-hipError_t gn_launch_level(const GNLevelArgs &args, const GNLaunchPlan &plan, int storage, int n_pairs,
+// args.n_pairs pairs, args.work_counter zeroed on the stream beforehand; the grid is min(pairs, CUs x workgroups/CU).
+hipError_t gn_launch_level(const GNLevelArgs &args, const GNLaunchPlan &plan, int storage, int cu_count,
                            hipStream_t stream);
 // Extension (PHOVO_SAMPLING_BILINEAR): single-pass kernel, 256 threads, no owner map, any level size.
-hipError_t gn_launch_level_bilinear(const GNLevelArgs &args, int storage, bool corrected, int n_pairs,
+hipError_t gn_launch_level_bilinear(const GNLevelArgs &args, int storage, bool corrected, int cu_count,
                                     hipStream_t stream);
 // Wide form (gn_wide_kernels.hip): many workgroups per pair, three launches per iteration; for a handful of
 // pairs on large levels.  fp64 planes, reference semantics only.

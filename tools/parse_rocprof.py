@@ -1,6 +1,9 @@
 """Turns the rocprofv3 outputs of one profiling session into the files kept under profiles/:
 
-    python tools/parse_rocprof.py gpurun_out/prof_r01 profiles r01
+    python tools/parse_rocprof.py gpurun_out/prof_r01 profiles r01 [--current] [--pairs 2048]
+
+--pairs is the number of frame pairs each profiled launch aligned (bench.py --pairs): the level kernels draw pairs
+from a work queue, so the grid size no longer says how many there were.
 
 Inputs (directories written by the commands in profiles/README.md):
   stats/      --kernel-trace --stats                     -> <tag>_kernel_stats.csv (copied)
@@ -36,6 +39,7 @@ def mean_by_kernel(rows, skip_first=0):
 
 def main():
     src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+    pairs = int(sys.argv[sys.argv.index("--pairs") + 1]) if "--pairs" in sys.argv else 2048
     os.makedirs(dst, exist_ok=True)
     for f in glob.glob(os.path.join(src, "stats", "**", "*_kernel_stats.csv"), recursive=True):
         shutil.copy(f, os.path.join(dst, f"{tag}_kernel_stats.csv"))
@@ -66,9 +70,10 @@ def main():
     for kd in out["kernels"]:
         m = re.search(r"gn_level_kernel<(\d+)", kd["kernel"])
         kd["threads"] = int(m.group(1)) if m else None
-        kd["pairs"] = kd["grid_size"] // kd["threads"] if kd["threads"] else None
+        kd["workgroups"] = kd["grid_size"] // kd["threads"] if kd["threads"] else None
+        kd["pairs"] = pairs
     json.dump(out, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
-    if len(sys.argv) > 4 and sys.argv[4] == "--current":      # the file bench.py reads for roofline.traffic
+    if "--current" in sys.argv:      # the file bench.py reads for roofline.traffic
         json.dump(out, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
