@@ -9,6 +9,9 @@
 #define PHOVO_HIP_CPHOTOCONSISTENCY_ODOMETRY_H
 
 #include <cmath>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
 
 #include "phovo/compat/Image.h"
 #include "phovo/compat/Numeric.h"
@@ -30,31 +33,24 @@ void eigenPose(const T x, const T y, const T z, const T yaw, const T pitch, cons
 
 // Forward-warps the source intensities into the target view for display
 // (reference: CPhotoconsistencyOdometry.h:73-134): depth > 0 gate, truncating cast, last writer wins.
+// Runs on the device (phovo_warp_image, csrc/warp_kernels.hip); like the class it is instantiable for
+// <unsigned char, double>, which is what both reference apps use, and throws when the device call fails.
 template <class TPixel, class TCoordinate>
 void warpImage(const compat::Mat_<TPixel> &intensityImage, const compat::Mat_<TCoordinate> &depthImage,
                compat::Mat_<TPixel> &warpedIntensityImage, const Numeric::Matrix44RowMajor<TCoordinate> &Rt,
-               const Numeric::Matrix33RowMajor<TCoordinate> &intrinsicMatrix, const int level = 0)
+               const Numeric::Matrix33RowMajor<TCoordinate> &intrinsicMatrix, const int level = 0,
+               const int device = 0)
 {
-  const TCoordinate s = (TCoordinate)std::pow(2, level);
-  const TCoordinate fx = intrinsicMatrix(0, 0) / s, fy = intrinsicMatrix(1, 1) / s;
-  const TCoordinate ox = intrinsicMatrix(0, 2) / s, oy = intrinsicMatrix(1, 2) / s;
-  const TCoordinate inv_fx = 1.f / fx, inv_fy = 1.f / fy;
-  const int H = intensityImage.rows, W = intensityImage.cols;
-  warpedIntensityImage = compat::Mat_<TPixel>::zeros(H, W);
-  for (int r = 0; r < H; r++) {
-    for (int c = 0; c < W; c++) {
-      const TCoordinate d = depthImage(r, c);
-      if (!(d > 0)) continue;
-      const TCoordinate p[4] = {(c - ox) * d * inv_fx, (r - oy) * d * inv_fy, d, 1};
-      TCoordinate q[3];
-      for (int a = 0; a < 3; a++)
-        q[a] = ((Rt(a, 0) * p[0] + Rt(a, 1) * p[1]) + Rt(a, 2) * p[2]) + Rt(a, 3) * p[3];
-      const TCoordinate tcd = ((q[0] * fx) / q[2]) + ox, trd = ((q[1] * fy) / q[2]) + oy;
-      if (!(tcd > -2147483648.0 && tcd < 2147483647.0 && trd > -2147483648.0 && trd < 2147483647.0)) continue;
-      const int tc = (int)tcd, tr = (int)trd;          // truncation, not rounding
-      if (tr >= 0 && tr < H && tc >= 0 && tc < W) warpedIntensityImage(tr, tc) = intensityImage(r, c);
-    }
-  }
+  static_assert(std::is_same<TPixel, unsigned char>::value && std::is_same<TCoordinate, double>::value,
+                "the MI355X path implements warpImage<unsigned char, double>");
+  if (depthImage.rows != intensityImage.rows || depthImage.cols != intensityImage.cols)
+    throw std::runtime_error("warpImage: intensity and depth sizes differ");
+  warpedIntensityImage = compat::Mat_<TPixel>::zeros(intensityImage.rows, intensityImage.cols);   // :98
+  const int status = phovo_warp_image(device, intensityImage.data, intensityImage.step, depthImage.data,
+                                      depthImage.step, intensityImage.cols, intensityImage.rows, Rt.data(),
+                                      intrinsicMatrix.data(), level, warpedIntensityImage.data,
+                                      warpedIntensityImage.step);
+  if (status != PHOVO_OK) throw std::runtime_error(std::string("warpImage: ") + phovo_last_error());
 }
 
 template <class TPixel, class TCoordinate>

@@ -127,6 +127,15 @@ int phovo_extensions_read_file(const char *path, phovo_extensions *ext);
 /* eigenPose, CPhotoconsistencyOdometry.h:47-71: (x,y,z,yaw,pitch,roll) -> row-major 4x4. */
 int phovo_eigen_pose(const double state[6], double rt[16]);
 
+/* warpImage, CPhotoconsistencyOdometry.h:73-134 -- the forward warp both reference apps call after Optimize()
+ * (...FrameAlignment.cpp:108, ...VisualOdometry.cpp:248-250) to show |I1 - warp(I0)|.  Host buffers in and out,
+ * strides in bytes; rt row-major 4x4, k row-major 3x3, level scales the intrinsics by 2^-level as the reference does.
+ * Reference semantics: depth > 0 gate, truncating cast of the projected position, the last source pixel in raster
+ * order that lands on a target pixel stays, zeros elsewhere. */
+int phovo_warp_image(int device, const uint8_t *intensity, size_t intensity_stride_bytes,
+                     const double *depth, size_t depth_stride_bytes, int w, int h, const double rt[16],
+                     const double k[9], int level, uint8_t *warped, size_t warped_stride_bytes);
+
 /* ---- single pair: 1:1 with CPhotoconsistencyOdometryAnalytic<unsigned char,double> ------- */
 int phovo_odometry_create(int device, phovo_odometry **out);               /* ctor  :430-443 */
 int phovo_odometry_destroy(phovo_odometry *o);                             /* dtor  :445     */

@@ -28,6 +28,24 @@ def _f64img(a):
     return a
 
 
+def warpImage(intensityImage, depthImage, Rt, intrinsicMatrix, level=0, device=0):
+    """phovo::warpImage (phovo/include/CPhotoconsistencyOdometry.h:73-134) on the device: forward warp of the source
+    intensities into the target view (depth > 0 gate, truncating cast, last raster writer wins, zeros elsewhere).
+    Returns the warped u8 image instead of filling an output argument."""
+    g, d = _u8(intensityImage), _f64img(depthImage)
+    if g.shape != d.shape:
+        raise ValueError("intensity and depth must have the same size")
+    h, w = g.shape
+    rt = np.ascontiguousarray(Rt, dtype=np.float64).reshape(16)
+    k = np.ascontiguousarray(intrinsicMatrix, dtype=np.float64).reshape(9)
+    out = np.empty((h, w), dtype=np.uint8)
+    dp = C.POINTER(C.c_double)
+    check(native.lib().phovo_warp_image(int(device), g.ctypes.data, w, d.ctypes.data, w * 8, w, h,
+                                        rt.ctypes.data_as(dp), k.ctypes.data_as(dp), int(level),
+                                        out.ctypes.data, w), "warpImage")
+    return out
+
+
 class CPhotoconsistencyOdometryAnalytic:
     """One frame pair at a time; 1:1 with the reference class."""
 
