@@ -204,6 +204,51 @@ __device__ __forceinline__ double fast_rcp(double x)
   return fma(r, e, r);
 }
 
+// C round() -- half away from zero (...Analytic.h:297-298) -- for arguments > -0.5, which is all the bounds test lets
+// through: trunc, exact fraction, +1 when the fraction reaches one half.  Five instructions; the library round() also
+// carries the sign through (seven).  (-0.5, 0) gives +0 where round() gives -0: both are pixel 0.
+__device__ __forceinline__ double round_half_up_from(double v)
+{
+  const double t = trunc(v);
+  const double f = v - t;                                              // exact
+  return t + __hiloint2double(f >= 0.5 ? 0x3ff00000 : 0, 0);          // + 1.0 or + 0.0: one select on the high word
+}
+
+// v_writelane_b32: lane `lane` (wave-uniform) of `old` becomes `value` (wave-uniform); the other lanes keep theirs.
+// clang has builtins for readlane / readfirstlane but none for writelane, so the LLVM intrinsic is declared by name
+// (the device libraries do the same for intrinsics without a builtin).  Inline assembly is not an option: the lane
+// select travels in M0 and the assembler's operand check then counts two scalar sources.
+extern "C" __device__ int phovo_llvm_writelane_i32(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+__device__ __forceinline__ int writelane_b32(int old, int value, int lane)
+{
+  return phovo_llvm_writelane_i32(value, lane, old);
+}
+
+// (row, column) of a lane's pixel, carried along as integer-valued doubles (exact), NW*64 pixels per step:
+// column += step_c, and on running past the row end column -= W, row += 1.  W, step_r and step_r + 1 are small
+// integers, so as doubles their low words are zero and each select is one v_cndmask on the high word.
+struct RowColStep {
+  double step_c, w;
+  int hi_w, hi_step_r, hi_step_r1;
+};
+__device__ __forceinline__ RowColStep make_rowcol_step(int step_r, int step_c, int W)
+{
+  RowColStep s;
+  s.step_c = (double)step_c;
+  s.w = (double)W;
+  s.hi_w = __double2hiint((double)W);
+  s.hi_step_r = __double2hiint((double)step_r);
+  s.hi_step_r1 = __double2hiint((double)(step_r + 1));
+  return s;
+}
+__device__ __forceinline__ void rowcol_advance(double &cd, double &rd, const RowColStep &s)
+{
+  cd += s.step_c;
+  const bool wrap = cd >= s.w;
+  cd -= __hiloint2double(wrap ? s.hi_w : 0, 0);
+  rd += __hiloint2double(wrap ? s.hi_step_r1 : s.hi_step_r, 0);
+}
+
 // Wave butterfly + cross-wave sum + solve + update + termination, as in gn_level_kernel's tail, for kernels
 // that keep their 27 sums in `acc`.  Returns after the closing barrier; the caller reads s_ctl[CTL_DONE].
 template <int NW>

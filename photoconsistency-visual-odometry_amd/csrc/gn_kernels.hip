@@ -125,6 +125,8 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
   const int k0 = wave * WAVE + lane;
   const int r0 = k0 / W, c0 = k0 - r0 * W;
   const int step_r = (NW * WAVE) / W, step_c = (NW * WAVE) - step_r * W;
+  const RowColStep rc_step = make_rowcol_step(step_r, step_c, W);
+  const double cd0 = (double)c0, rd0 = (double)r0;
 
   int iteration = 0;
   double last_gnorm = 0.0;
@@ -144,45 +146,67 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
     const double t14 = uniform_f64(s_cst[C_T14]), t15 = uniform_f64(s_cst[C_T15]);
 
     // ---- pass 1: warp every source pixel, resolve who owns each target pixel -------------
-    unsigned long long inb_bits = 0ull;
+    // MASK_REG: chunk j's "landed in bounds" ballot lives in lane j of two registers (v_writelane here, v_readlane
+    // + exec mask in pass 2): no per-lane shifting and masking in either pass
+    int inb_lo = 0, inb_hi = 0;
     {
-      int k = k0, r = r0, c = c0, j = 0;
+      int k = k0, j = 0;
+      double cd = cd0, rd = rd0;
       // software prefetch: the depth of the NEXT chunk is requested before this chunk is processed, so
       // every wave keeps a load in flight while it computes (the passes are bound by bytes in flight per CU)
       double pz_next = plane_load<TD>(rD0, k);
-#pragma unroll 2
-      for (int chunk = wave; chunk < A.n_chunks; chunk += NW, j++) {
+      // the translation sits in vector registers during this pass (pass 1 has registers to spare): an fma takes one
+      // scalar operand, and the rotation entry already is one
+      double cxv = cx, cyv = cyy, czv = cz;
+      asm volatile("" : "+v"(cxv), "+v"(cyv), "+v"(czv));
+      auto chunk_body = [&](const int chunk) {
         const double pz = pz_next;                                        // :279
         pz_next = plane_load<TD>(rD0, k + NW * WAVE);                     // past the plane: 0
-        bool inb = false;
-        {
-          if (k < n && min_d < pz && pz < max_d) {                        // :280
-            const double px = ((double)c - ox) * pz * ifx;                // :282
-            const double py = ((double)r - oy) * pz * ify;                // :283
-            const double X = ((t15 * px + r01 * py) + r02 * pz) + cx;     // Rt*point3D  :291
-            const double Y = ((t14 * px + r11 * py) + r12 * pz) + cyy;
-            const double Z = ((-t3 * px + t1 * py) + t2 * pz) + cz;
-            const double iz = fast_rcp(Z);                                // :294
-            const double tc = (X * fx) * iz + ox;                         // :295
-            const double tr = (Y * fy) * iz + oy;                         // :296
-            const double rr = round(tr), rc = round(tc);                  // C round(), half away  :297-298
-            if (rr >= 0.0 && rr < dH && rc >= 0.0 && rc < dW) {           // :302-303 (NaN fails)
-              inb = true;
-              const int t = __mul24((int)rr, W) + (int)rc;           // both < 2^24: full-rate 24-bit multiply
-              if (OWNER_LDS) atomicMax(&s_owner[t], k);                   // last raster writer wins  :358
-              else atomicMax(&g_owner[t], k);
-            }
-          }
+        // No branch around the arithmetic: a lane that fails the depth gate computes on whatever it loaded and is
+        // dropped by `valid` below (a whole wave of invalid pixels is rare), and the ballot of a flat condition is
+        // the AND of the compare masks -- scalar work only.
+        // depth gate: k < n, min_d < pz < max_d  (:280), folded into the ballot below
+        const double px = (cd - ox) * pz * ifx;                           // :282
+        const double py = (rd - oy) * pz * ify;                           // :283
+        const double X = fma(r02, pz, fma(r01, py, fma(t15, px, cxv)));   // Rt*point3D  :291
+        const double Y = fma(r12, pz, fma(r11, py, fma(t14, px, cyv)));
+        const double Z = fma(t2, pz, fma(t1, py, fma(-t3, px, czv)));
+        const double iz = fast_rcp(Z);                                    // :294
+        const double tc = (X * fx) * iz + ox;                             // :295
+        const double tr = (Y * fy) * iz + oy;                             // :296
+        // C round(), half away from zero (:297-298), then 0 <= . < size (:302-303): round(v) >= 0 iff v > -0.5
+        // (NaN fails every comparison)
+        const double rr = round_half_up_from(tr), rc = round_half_up_from(tc);
+        // One ballot per comparison, ANDed on the scalar unit: the ballot of an AND of comparisons would be
+        // rebuilt lane by lane (v_cndmask + v_cmp) by this compiler.
+        const unsigned long long m =
+            __builtin_amdgcn_ballot_w64(k < n) & __builtin_amdgcn_ballot_w64(min_d < pz) &
+            __builtin_amdgcn_ballot_w64(pz < max_d) & __builtin_amdgcn_ballot_w64(tr > -0.5) &
+            __builtin_amdgcn_ballot_w64(rr < dH) & __builtin_amdgcn_ballot_w64(tc > -0.5) &
+            __builtin_amdgcn_ballot_w64(rc < dW);
+        if (__builtin_amdgcn_inverse_ballot_w64(m)) {
+          const int t = (int)fma(rr, dW, rc);                             // exact in fp64: one fma + one conversion
+          if (OWNER_LDS) atomicMax(&s_owner[t], k);                       // last raster writer wins  :358
+          else atomicMax(&g_owner[t], k);
         }
         if (MASK_REG) {
-          inb_bits |= (unsigned long long)(inb ? 1u : 0u) << j;
+          inb_lo = writelane_b32(inb_lo, (int)(unsigned)m, j);
+          inb_hi = writelane_b32(inb_hi, (int)(unsigned)(m >> 32), j);
         } else {
-          const unsigned long long m = __ballot(inb);
           if (lane == 0) s_mask[chunk] = m;
         }
-        k += NW * WAVE; c += step_c; r += step_r;
-        if (c >= W) { c -= W; r += 1; }
+        k += NW * WAVE;
+        j++;
+        rowcol_advance(cd, rd, rc_step);
+      };
+      // two chunks per trip, written out by hand: the ballot / lane accesses are convergent operations, which the
+      // compiler will not duplicate for a run-time trip count (#pragma unroll is refused); the bounds are wave-uniform
+      int chunk = wave;
+      for (; chunk + NW < A.n_chunks; chunk += 2 * NW) {
+        chunk_body(chunk);
+        chunk_body(chunk + NW);
       }
+      if (chunk < A.n_chunks) chunk_body(chunk);
     }
     PHOVO_STAMP(0)
     __syncthreads();
@@ -203,7 +227,8 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
     // reference path (no Huber weights) carries none of the extension's instructions.
     auto pass2 = [&](auto huber_tag) {
       constexpr bool HUBER = decltype(huber_tag)::value;
-      int k = k0, r = r0, c = c0, j = 0;
+      int k = k0, j = 0;
+      double cd = cd0, rd = rd0;
       // software prefetch, as in pass 1: owner + four planes of the NEXT chunk are requested (and the
       // gathered source intensity right behind them) before this chunk's arithmetic starts.
       int o_n = -1;
@@ -227,17 +252,18 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
         else i0_n = plane_load<TI>(rI0, o_n);       // :308 of the owning source pixel (o = -1: offset past the plane -> 0)
       };
       fetch(k);
-#pragma unroll 2
-      for (int chunk = wave; chunk < A.n_chunks; chunk += NW, j++) {
+      auto chunk_body = [&](const int chunk) {
         const int o = o_n;
         const double pz = pz_n, gxi = gx_n, gyi = gy_n, pixel2 = i1_n, pixel1 = i0_n;
         fetch(k + NW * WAVE);
-        const bool mine = MASK_REG ? (((inb_bits >> j) & 1ull) != 0ull)
-                                   : (((s_mask[chunk] >> lane) & 1ull) != 0ull);
-        if (mine) {
+        const unsigned long long mbits =
+            MASK_REG ? (((unsigned long long)(unsigned)__builtin_amdgcn_readlane(inb_hi, j) << 32) |
+                        (unsigned long long)(unsigned)__builtin_amdgcn_readlane(inb_lo, j))
+                     : s_mask[chunk];
+        if (__builtin_amdgcn_inverse_ballot_w64(mbits)) {                 // the ballot becomes the exec mask
           const double res = (o >= 0) ? (pixel2 - pixel1) : 0.0;          // :358
-          const double px = ((double)c - ox) * pz * ifx;
-          const double py = ((double)r - oy) * pz * ify;
+          const double px = (cd - ox) * pz * ifx;
+          const double py = (rd - oy) * pz * ify;
 
           // The 2x6 warp Jacobian (:312-342) contracted with the image gradient (:348), with the common
           // factors pulled out and the reference's temps folded by exact algebraic identities:
@@ -287,8 +313,14 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
 #pragma unroll
           for (int a = 0; a < 6; a++) acc[21 + a] = fma(Jw[a], res, acc[21 + a]);        // J^T (W) r  :538
         }
-        k += NW * WAVE; c += step_c; r += step_r;
-        if (c >= W) { c -= W; r += 1; }
+        k += NW * WAVE;
+        j++;
+        rowcol_advance(cd, rd, rc_step);
+      };
+      // two chunks per trip by hand, as in pass 1
+      for (int chunk = wave; chunk < A.n_chunks; chunk += 2 * NW) {
+        chunk_body(chunk);
+        if (chunk + NW < A.n_chunks) chunk_body(chunk + NW);
       }
     };
     if (huber_on) pass2(std::true_type{}); else pass2(std::false_type{});

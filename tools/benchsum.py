@@ -1,2 +1,19 @@
-import sys,json
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d["value"]), round(d["ms_per_step"],3), [ (l["level"], round(l["avg_launch_ms"],3), round(l["achieved_GBs"]), l["threads"], l["lds_bytes"]) for l in d["roofline"]["levels"]], "ref-term", round(d["reference_termination"]["value"]))
+"""One line per bench.py JSON output: python tools/benchsum.py a.json b.json ...  (no arguments: reads stdin)."""
+import json
+import sys
+
+
+def line(text, tag=""):
+    d = json.loads(text.strip().splitlines()[-1])
+    lv = [(l["level"], round(l["avg_launch_ms"], 3), round(l["achieved_GBs"]), l["threads"], l["lds_bytes"])
+          for l in d["roofline"]["levels"]]
+    rt = d.get("reference_termination") or {}
+    print(tag, round(d["value"]), round(d["ms_per_step"], 3), "frac", round(d["roofline"]["frac"], 3), lv,
+          "ref-term", round(rt.get("value", 0)))
+
+
+if len(sys.argv) > 1:
+    for f in sys.argv[1:]:
+        line(open(f).read(), f)
+else:
+    line(sys.stdin.read())

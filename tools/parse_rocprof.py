@@ -10,6 +10,9 @@ Inputs (directories written by the commands in profiles/README.md):
   pmc_fetch/  --pmc FETCH_SIZE   of the same bench command
   pmc_write/  --pmc WRITE_SIZE   of the same bench command
   cal_fetch/, cal_write/   the same counters on tools/pmc_calibrate.py (a copy kernel of known size)
+  pmc_sq/     --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU
+              SQ_BUSY_CYCLES GRBM_GUI_ACTIVE of the same bench command (optional) -> <tag>_pmc_sq.json:
+              where the wave cycles go, VALU instructions per launch and the effective clock
 Output: <tag>_pmc_traffic.json (+ pmc_traffic.json for bench.py) with HBM bytes per launch of each
 Gauss-Newton level kernel, corrected as MI355X_MICROARCH.md (HBM section) prescribes: the counters are
 calibrated on a known byte count in the kernel's own access pattern (8 B per lane, coalesced) and the
@@ -35,6 +38,40 @@ def mean_by_kernel(rows, skip_first=0):
     for r in rows:
         acc[(r["Kernel_Name"], int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
     return {k: sum(v[skip_first:]) / max(1, len(v[skip_first:])) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
+
+
+def sq_summary(rows, pairs):
+    """Per level kernel: mean of every SQ/GRBM counter over the timed dispatches (first two = warm-up) and the
+    ratios MI355X_MICROARCH.md names: WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES (per wave, in
+    quad-cycles); effective clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel duration."""
+    acc = defaultdict(lambda: defaultdict(list))
+    dur = defaultdict(dict)
+    for r in rows:
+        if "gn_level_kernel" not in r["Kernel_Name"]:
+            continue
+        acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        dur[r["Kernel_Name"]][r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    out = []
+    for k, d in sorted(acc.items()):
+        m = {c: sum(v[2:]) / max(1, len(v[2:])) for c, v in d.items()}
+        t = sorted(dur[k].items(), key=lambda kv: int(kv[0]))
+        t = [v for _, v in t][2:]
+        ns = sum(t) / max(1, len(t))
+        wc = m.get("SQ_WAVE_CYCLES", 0.0)
+        e = dict(kernel=k, pairs=pairs, dispatches=len(t), mean_duration_ns=ns, counters=m)
+        if wc > 0:
+            e["fraction_of_wave_cycles"] = {
+                "parked (SQ_WAIT_ANY: s_waitcnt / barrier)": m.get("SQ_WAIT_ANY", 0.0) / wc,
+                "issue stall (SQ_WAIT_INST_ANY)": m.get("SQ_WAIT_INST_ANY", 0.0) / wc,
+                "issuing (SQ_ACTIVE_INST_ANY)": m.get("SQ_ACTIVE_INST_ANY", 0.0) / wc,
+                "issuing VALU (SQ_ACTIVE_INST_VALU)": m.get("SQ_ACTIVE_INST_VALU", 0.0) / wc,
+            }
+            # 4 waves per SIMD share one vector unit: the per-wave VALU share times 4 is the unit's busy fraction
+            e["simd_valu_busy_at_4_waves"] = 4.0 * m.get("SQ_ACTIVE_INST_VALU", 0.0) / wc
+        if ns > 0 and "GRBM_GUI_ACTIVE" in m:
+            e["effective_clock_GHz"] = m["GRBM_GUI_ACTIVE"] / 8.0 / ns
+        out.append(e)
+    return out
 
 
 def main():
@@ -73,6 +110,10 @@ def main():
         kd["workgroups"] = kd["grid_size"] // kd["threads"] if kd["threads"] else None
         kd["pairs"] = pairs
     json.dump(out, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+    sq = sq_summary(counter_rows(os.path.join(src, "pmc_sq")), pairs)
+    if sq:
+        json.dump(dict(tag=tag, kernels=sq), open(os.path.join(dst, f"{tag}_pmc_sq.json"), "w"), indent=1)
+        print(json.dumps(sq, indent=1))
     if "--current" in sys.argv:      # the file bench.py reads for roofline.traffic
         json.dump(out, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))

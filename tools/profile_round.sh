@@ -16,6 +16,8 @@ timeout -k 10 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fe
 timeout -k 10 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $BENCH > "$OUT/pmc_write.log" 2>&1
 timeout -k 10 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/cal_fetch" -- python3 $ROOT/tools/pmc_calibrate.py > "$OUT/cal_fetch.log" 2>&1
 timeout -k 10 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/cal_write" -- python3 $ROOT/tools/pmc_calibrate.py > "$OUT/cal_write.log" 2>&1
+# where the wave cycles go (issue vs parked), VALU share and the effective clock: one SQ pass + GRBM
+timeout -k 10 240 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_sq" -- $BENCH > "$OUT/pmc_sq.log" 2>&1
 # keep what travels back small: the per-dispatch traces are not needed, the stats and counter tables are
 find "$OUT" -name "*_kernel_trace.csv" -size +8M -delete
 echo "profiles collected under $OUT"
