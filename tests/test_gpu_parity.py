@@ -471,3 +471,45 @@ def test_wide_form_equals_persistent_form_and_oracle(size, levels, max_iter, min
         assert se3.state_distance(sw[i], es) < POSE_TOL and se3.state_distance(sp[i], es) < POSE_TOL
         assert abs(rw[i].gradient_norm - rp[i].gradient_norm) <= 1e-9 * max(1.0, rp[i].gradient_norm)
     assert np.array_equal(sw, sw2)
+
+
+@pytest.mark.parametrize("yml,fixed", [("config_5_level_optimization_analytic.yml", False),
+                                       ("config_4_level_optimization_analytic.yml", False),
+                                       ("config_5_level_optimization_analytic.yml", True)])
+def test_work_queue_results_do_not_depend_on_position_or_history(yml, fixed):
+    """The level kernels run a persistent grid whose workgroups draw pair after pair from a queue.  2500 pairs (more
+    than the resident workgroups of any variant) cycle in shuffled order over three problems of different
+    difficulty: every copy must come out bit-identical -- whatever the workgroup aligned before, with however many
+    iterations -- and equal the oracle."""
+    ncfg = native.read_config_file(os.path.join(CFG_DIR, yml))
+    nl = ncfg.num_levels
+    max_iter, min_grad = list(ncfg.max_num_iterations[:nl]), list(ncfg.min_gradient_norm[:nl])
+    if fixed:                                   # every active level runs 5 iterations on every pair
+        max_iter, min_grad = [min(m, 5) for m in max_iter], [0.0] * nl
+    ncfg, ocfg = _cfgs(nl, max_iter, min_grad)
+    probs = [synthetic.make_pair(21, 640, 480, holes=0.02, trans=0.004, rot=0.002),
+             synthetic.make_pair(22, 640, 480, holes=0.0, trans=0.03, rot=0.015),
+             synthetic.make_pair(23, 640, 480, holes=0.05, trans=0.06, rot=0.03)]
+    expect = [oracle.align_frames(ocfg, p["K"], p["gray0"], p["depth0"], p["gray1"]) for p in probs]
+    if not fixed:
+        assert len({tuple(e[1]) for e in expect}) > 1, "the three problems should stop after different iteration counts"
+    order = np.random.RandomState(5).randint(0, 3, size=2500)
+    with odometry.AlignmentEngine() as eng:
+        eng.set_config(ncfg)
+        eng.set_intrinsic_matrix(probs[0]["K"])
+        eng.reserve_frames(6, 640, 480)
+        for i, p in enumerate(probs):
+            eng.upload_frame(2 * i, p["gray0"], p["depth0"], roles=native.ROLE_SOURCE)
+            eng.upload_frame(2 * i + 1, p["gray1"], None, roles=native.ROLE_TARGET)
+        states, reps = eng.align_pairs([2 * int(i) for i in order], [2 * int(i) + 1 for i in order], want_reports=True)
+    first = {}
+    for pos, i in enumerate(order):
+        i = int(i)
+        if i not in first:
+            first[i] = pos
+            assert list(reps[pos].iterations[:nl]) == expect[i][1], (i, list(reps[pos].iterations[:nl]), expect[i][1])
+            assert se3.state_distance(states[pos], expect[i][0]) < POSE_TOL
+        else:
+            assert np.array_equal(states[pos], states[first[i]]), (pos, i)
+            assert list(reps[pos].iterations[:nl]) == list(reps[first[i]].iterations[:nl])
+        assert reps[pos].flags == 0
