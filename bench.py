@@ -242,6 +242,28 @@ def main():
                    note="host buffers in (u8 gray + u16 depth, 0.92 MB/frame over PCIe), device pyramids, Optimize() "
                         "with the shipped thresholds, poses out; bound by PCIe, not by the alignment kernels")
 
+    # ---- one pair at a time through the class surface (BASELINE.json configs[1] read literally; never `value`) ----
+    single = None
+    if rank == 0 and world == 1 and not args.no_reference_termination and plain_mode and args.storage == "f64":
+        single = {}
+        with odometry.CPhotoconsistencyOdometryAnalytic(local_rank) as po:
+            po.SetIntrinsicMatrix(seq["K"])
+            for name, cfg_one in (("shipped_thresholds", cfg_ref), ("fixed_iterations", cfg_fixed)):
+                po.SetConfiguration(cfg_one)
+                po.SetSourceFrame(seq["gray"][0], seq["depth"][0])
+                po.SetTargetFrame(seq["gray"][1], seq["depth"][1])
+                dev_ms, wall_ms = [], []
+                for _ in range(20):
+                    po.SetInitialStateVector(np.zeros(6))
+                    t0 = time.perf_counter()
+                    po.Optimize()
+                    wall_ms.append((time.perf_counter() - t0) * 1e3)
+                    dev_ms.append(po.LastOptimizeMilliseconds())
+                single[name] = dict(device_ms=float(np.median(dev_ms)), host_wall_ms=float(np.median(wall_ms)),
+                                    iterations=[int(v) for v in po.GetReport().iterations[:nl]])
+        single["note"] = ("one 640x480 pair per Optimize() call (SetSourceFrame/SetTargetFrame outside the timer, as the "
+                          "reference's FrameAlignment app times it): latency-bound, one workgroup per level")
+
     # ---- CPU baseline: the oracle, one thread, bounded sample of the same workload ------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -323,6 +345,7 @@ def main():
             "cpu_baseline_all_cores": cpu_all,
             "reference_termination": ref_term,
             "end_to_end_pcie_inclusive": e2e,
+            "single_pair": single,
         }
         print(json.dumps(out))
     eng.close()

@@ -795,6 +795,8 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
     PHOVO_HIP_CHECK(hipMemsetAsync(e->d_states, 0, sizeof(double) * 6 * (size_t)n_pairs, e->stream));
   PHOVO_HIP_CHECK(hipMemsetAsync(e->d_reports, 0, sizeof(phovo_pair_report) * (size_t)n_pairs, e->stream));
 
+  // the work-queue heads of all levels (one int each), cleared by one node ahead of the level launches
+  PHOVO_HIP_CHECK(hipMemsetAsync(e->d_work_counters, 0, sizeof(int) * PHOVO_MAX_LEVELS, e->stream));
   for (int l = e->cfg.num_levels - 1; l >= 0; l--) {                                 // coarse to fine  :502-503
     if (e->cfg.max_num_iterations[l] <= 0) continue;                                 // :526 (nothing observable happens)
     const LevelPool &lv = e->levels[l];
@@ -818,7 +820,6 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
     a.g_owner = e->d_owner;
     a.n_pairs = n_pairs;
     a.work_counter = e->d_work_counters + l;
-    PHOVO_HIP_CHECK(hipMemsetAsync(e->d_work_counters + l, 0, sizeof(int), e->stream));
     PHOVO_HIP_CHECK(hipEventRecord(e->ev_start[l], e->stream));
     if (e->ext.sampling == PHOVO_SAMPLING_BILINEAR)
       PHOVO_HIP_CHECK(gn_launch_level_bilinear(a, e->ext.plane_storage, e->ext.jacobian_corrected != 0, e->cu_count, e->stream));
