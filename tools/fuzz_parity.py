@@ -3,7 +3,10 @@ half-integers, depth holes / NaN / out-of-range depth, large motions, non-zero i
 the sizes select, optionally narrow storage / Huber / bilinear.  Prints one line per failure and a summary; exit code 1
 if any case misses the 1e-9 pose bar or an iteration count.
 
-    python tools/fuzz_parity.py [cases=150] [seed=0]
+    python tools/fuzz_parity.py [cases=150] [seed=0] [ext]
+
+With `ext` every case also draws a combination of the opt-in extensions (fp32 / fp16 plane storage, Huber weights,
+bilinear sampling with or without the corrected Jacobian); the oracle is then fed the planes as the device stored them.
 """
 import os
 import sys
@@ -17,6 +20,7 @@ from oracle import oracle  # noqa: E402
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+with_ext = len(sys.argv) > 3 and sys.argv[3] == "ext"
 bad, worst, variants = 0, 0.0, {}
 for case in range(cases):
     nl = int(rs.randint(1, 4))
@@ -46,13 +50,38 @@ for case in range(cases):
     ncfg = native.make_config(num_levels=nl, max_iter=max_iter, min_grad=min_grad, lam=lam)
     ocfg = oracle.make_config(num_levels=nl, max_iter=max_iter, min_grad=min_grad, lam=lam)
     init = None if rs.rand() < 0.5 else rs.uniform(-1, 1, 6) * np.array([0.02, 0.02, 0.02, 0.01, 0.01, 0.01])
-    es, eits = oracle.align_frames(ocfg, K, p["gray0"], d0, p["gray1"], init_state=init)[:2]
+    storage, huber, bilinear, corrected = native.STORAGE_F64, None, False, False
+    if with_ext:
+        storage = [native.STORAGE_F64, native.STORAGE_F32, native.STORAGE_F16][int(rs.randint(0, 3))]
+        huber = None if rs.rand() < 0.4 else [float(rs.choice([0.0, 0.02, 0.1])) for _ in range(nl)]
+        bilinear = rs.rand() < 0.5
+        corrected = bool(bilinear and rs.rand() < 0.5)
+    else:
+        es, eits = oracle.align_frames(ocfg, K, p["gray0"], d0, p["gray1"], init_state=init)[:2]
     with odometry.AlignmentEngine() as eng:
         eng.set_config(ncfg)
+        if with_ext:
+            eng.set_extensions(native.make_extensions(
+                plane_storage=storage, huber_delta=huber,
+                sampling=native.SAMPLING_BILINEAR if bilinear else native.SAMPLING_NEAREST_SCATTER,
+                jacobian_corrected=corrected))
         eng.set_intrinsic_matrix(K)
         eng.reserve_frames(2, w, h)
         eng.upload_frame(0, p["gray0"], d0, roles=native.ROLE_SOURCE)
         eng.upload_frame(1, p["gray1"], None, roles=native.ROLE_TARGET)
+        if with_ext:                       # oracle inputs = the planes as stored (rounded once to the storage type)
+            planes = [[], [], [], [], []]
+            for l in range(nl):
+                if max_iter[l] > 0:
+                    i0, dd, _, _ = eng.get_level_planes(0, l)
+                    i1, _, gx, gy = eng.get_level_planes(1, l)
+                else:
+                    lw, lh = oracle.level_size(w, h, l)
+                    i0 = dd = i1 = gx = gy = np.zeros((lh, lw))
+                for lst, v in zip(planes, (i0, dd, i1, gx, gy)):
+                    lst.append(v)
+            es, eits = oracle.optimize(ocfg, K, *planes, init_state=init, huber_delta=huber, bilinear=bilinear,
+                                       corrected=corrected)[:2]
         n_pairs = int(rs.choice([1, 3, 40]))          # 40 > 32: never the wide form
         inits = None if init is None else np.tile(init, (n_pairs, 1))
         s, reps = eng.align_pairs([0] * n_pairs, [1] * n_pairs, init_states=inits, want_reports=True)
@@ -73,7 +102,8 @@ for case in range(cases):
     if not ok:
         bad += 1
         print(f"FAIL case {case}: {w}x{h} levels {nl} max_iter {max_iter} min_grad {min_grad} pairs {n_pairs} "
-              f"iterations gpu {its} cpu {eits} distance {d:.3e} flags {reps[0].flags}")
+              f"iterations gpu {its} cpu {eits} distance {d:.3e} flags {reps[0].flags} "
+              f"ext(storage {storage}, huber {huber}, bilinear {bilinear}, corrected {corrected})")
 print(f"{cases} cases, {bad} failures, worst pose distance {worst:.3e}")
 print("launch geometries exercised (threads, owner in LDS, source in LDS, wide form): ", variants)
 sys.exit(1 if bad else 0)
