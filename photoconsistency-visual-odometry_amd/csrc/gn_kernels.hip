@@ -76,6 +76,11 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
   // barrier with thread 0 parked: a hang).
   if (tid == 0) s_ctl[CTL_PAIR] = atomicAdd(A.work_counter, 1);
   for (;;) {
+  // The ticket thread 0 has just stored must have LEFT its LDS queue before any wave is released: the compiler omits
+  // the wait in front of this one barrier (it relies on LDS operations being ordered across waves), and on the GPU
+  // about one wave in 10^5 then read the previous ticket and aligned the wrong pair's pixels into this pair's sums --
+  // or, on the last round, would never have left the loop.  Found by test_work_queue_results_do_not_depend_on_...
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();
   const int pair = __builtin_amdgcn_readfirstlane(s_ctl[CTL_PAIR]);
   if (pair >= A.n_pairs) break;           // uniform: every wave of the workgroup leaves together
@@ -133,6 +138,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
 #ifdef PHOVO_STAMPS
   unsigned long long st_sum[5] = {0, 0, 0, 0, 0};
   unsigned long long st_prev = clock64();
+  const unsigned long long st_begin = wall_clock64();       // 100 MHz, common to all CUs: when this pair's first iteration began
 #define PHOVO_STAMP(i) { unsigned long long _n = clock64(); st_sum[i] += _n - st_prev; st_prev = _n; }
 #else
 #define PHOVO_STAMP(i)
@@ -402,6 +408,10 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
 #ifdef PHOVO_STAMPS
       // diagnostic build only: phase cycle sums of wave 0 go to the otherwise unused report slots 8..12
       for (int j = 0; j < 5; j++) A.reports[pair].iterations[8 + j] = (int)(st_sum[j] / (unsigned long long)iteration);
+      // slots 13..15 (last level launched wins): begin / end of the pair on the 100 MHz wall clock, and the workgroup
+      A.reports[pair].iterations[13] = (int)(unsigned)st_begin;
+      A.reports[pair].iterations[14] = (int)(unsigned)wall_clock64();
+      A.reports[pair].iterations[15] = (int)blockIdx.x;
 #endif
     }
     s_ctl[CTL_PAIR] = atomicAdd(A.work_counter, 1);
@@ -434,6 +444,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel_bilinear(const GNLevel
   const int n = A.n, W = A.w, H = A.h;
   if (tid == 0) s_ctl[CTL_PAIR] = atomicAdd(A.work_counter, 1);
   for (;;) {                                // work queue, as in gn_level_kernel
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // see gn_level_kernel
   __syncthreads();
   const int pair = __builtin_amdgcn_readfirstlane(s_ctl[CTL_PAIR]);
   if (pair >= A.n_pairs) break;
@@ -680,6 +691,8 @@ hipError_t launch_bilinear_storage(const GNLevelArgs &a, bool corrected, int n_b
   else hipLaunchKernelGGL((gn_level_kernel_bilinear<256, BILINEAR_WPS, TI, TD, false>), grid, block, lds, stream, a);
   return hipGetLastError();
 }
+
+int gn_bilinear_wgs_per_cu() { return BILINEAR_WPS; }
 
 hipError_t gn_launch_level_bilinear(const GNLevelArgs &a, int storage, bool corrected, int cu_count,
                                     hipStream_t stream)

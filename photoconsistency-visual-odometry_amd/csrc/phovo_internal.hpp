@@ -55,6 +55,7 @@ hipError_t gn_launch_level(const GNLevelArgs &args, const GNLaunchPlan &plan, in
 // Extension (PHOVO_SAMPLING_BILINEAR): single-pass kernel, 256 threads, no owner map, any level size.
 hipError_t gn_launch_level_bilinear(const GNLevelArgs &args, int storage, bool corrected, int cu_count,
                                     hipStream_t stream);
+int gn_bilinear_wgs_per_cu();      // workgroups of the bilinear kernel that stay resident per CU
 // Wide form (gn_wide_kernels.hip): many workgroups per pair, three launches per iteration; for a handful of
 // pairs on large levels.  fp64 planes, reference semantics only.
 size_t gn_wide_workspace_bytes(int n, int n_pairs);

@@ -502,6 +502,12 @@ def test_work_queue_results_do_not_depend_on_position_or_history(yml, fixed):
             eng.upload_frame(2 * i, p["gray0"], p["depth0"], roles=native.ROLE_SOURCE)
             eng.upload_frame(2 * i + 1, p["gray1"], None, roles=native.ROLE_TARGET)
         states, reps = eng.align_pairs([2 * int(i) for i in order], [2 * int(i) + 1 for i in order], want_reports=True)
+        # The hand-over of the next pair index inside a workgroup once went wrong about once per 30 000 pairs (a wave
+        # read the previous index from LDS: DESIGN.md section 3.1), i.e. in one launch of this size out of ten:
+        # repeat the launch so that such a rate cannot pass unnoticed.
+        for _ in range(25):
+            again = eng.align_pairs([2 * int(i) for i in order], [2 * int(i) + 1 for i in order])
+            assert np.array_equal(again, states)
     first = {}
     for pos, i in enumerate(order):
         i = int(i)

@@ -6,7 +6,11 @@ They pin two properties that no CPU-side numerical test can see and that cost a 
   barrier.  When the write-back block and the draw of the next pair were two adjacent `if (tid == 0)` blocks, one either
   side of the back edge, the compiler threaded them into a loop that reached this barrier with thread 0 parked outside
   it, and every workgroup spun forever on the pair it had just finished;
-* register spills stay out of the pixel loops (the kernels sit at the 128-VGPR cap of 4 waves per SIMD).
+* register spills stay out of the pixel loops (the kernels sit at the 128-VGPR cap of 4 waves per SIMD);
+* every workgroup barrier is preceded, in its own basic block, by `s_waitcnt lgkmcnt(0)`.  The compiler left that wait
+  out in front of the work loop's barrier (it counts on LDS operations being ordered across waves); on the GPU about one
+  wave in 10^5 then read the PREVIOUS pair's ticket from LDS and summed the wrong pair's pixels into the new pair's
+  normal equations (one wrong pose per ~30 000, no error raised).  The kernels now say the wait explicitly.
 """
 import os
 import re
@@ -39,13 +43,49 @@ def _first_instruction(body, i):
 
 
 def test_work_loop_head_is_the_barrier(kernels):
+    """From the header of the outermost loop the code must fall straight into the workgroup barrier: nothing that
+    branches or narrows the exec mask may come first (register spill moves and waits may)."""
     for name, body in kernels.items():
         heads = [i for i, l in enumerate(body) if "This Loop Header: Depth=1" in l]
         assert len(heads) == 1, f"{name}: expected exactly one outermost loop (the work queue), found {len(heads)}"
-        first = _first_instruction(body, heads[0])
-        if first.startswith("s_waitcnt"):
-            first = _first_instruction(body, body.index(next(l for l in body[heads[0]:] if l.strip() == first)))
-        assert first == "s_barrier", f"{name}: work loop starts with '{first}', not with the barrier"
+        i, waited = heads[0] + 1, False
+        while True:
+            t = body[i].strip()
+            i += 1
+            if not t or t.startswith(";"):
+                continue
+            if t == "s_barrier":
+                break
+            if t.startswith("s_waitcnt") and "lgkmcnt(0)" in t:
+                waited = True
+                continue
+            harmless = t.startswith(("s_waitcnt", "s_nop", "v_writelane_b32", "v_readlane_b32", "s_mov_b32", "v_mov_b32",
+                                     "scratch_"))
+            assert harmless, f"{name}: '{t}' between the work loop's header and its barrier"
+        assert waited, f"{name}: no s_waitcnt lgkmcnt(0) in front of the work loop's barrier"
+
+
+def test_every_barrier_waits_for_lds_first():
+    subprocess.run(["make", "-s", "-C", CSRC, "isa"], check=True, capture_output=True)
+    total = 0
+    for name in ("gn_kernels", "gn_wide_kernels", "pyramid_kernels", "warp_kernels"):
+        lines = open(os.path.join(CSRC, "build", name + ".s")).read().split("\n")
+        for i, l in enumerate(lines):
+            if l.strip() != "s_barrier":
+                continue
+            total += 1
+            j, verdict = i - 1, None
+            while j >= 0 and verdict is None:
+                t = lines[j].strip()
+                if t.startswith("s_waitcnt") and "lgkmcnt(0)" in t:
+                    verdict = "ok"
+                elif t.startswith("ds_"):
+                    verdict = f"LDS instruction '{t}' between the last wait and the barrier"
+                elif re.match(r"^(\.LBB\d+_\d+|_Z\w+):", t):
+                    verdict = "no s_waitcnt lgkmcnt(0) in the barrier's basic block"
+                j -= 1
+            assert verdict == "ok", f"{name}.s line {i + 1}: {verdict}"
+    assert total >= 50, "expected the barriers of all level-kernel instantiations"
 
 
 def test_two_draws_from_the_queue(kernels):
