@@ -25,8 +25,13 @@ bool load(const std::string &path, Raw *raw, std::string *err)
   std::vector<uint8_t> buf;
   uint8_t tmp[65536];
   size_t n;
-  while ((n = std::fread(tmp, 1, sizeof(tmp), f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
+  while ((n = std::fread(tmp, 1, sizeof(tmp), f)) > 0) {
+    buf.insert(buf.end(), tmp, tmp + n);
+    if (n < sizeof(tmp)) break;               // end of file or error: do not read again
+  }
+  const bool read_error = std::ferror(f) != 0;
   std::fclose(f);
+  if (read_error) { *err = path + ": read error"; return false; }
   static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
   if (buf.size() < 8 || std::memcmp(buf.data(), sig, 8) != 0) { *err = path + ": not a PNG file"; return false; }
   std::vector<uint8_t> idat;
