@@ -31,8 +31,13 @@ import phovo_amd  # noqa: E402,F401
 from phovo_amd import distributed, native, odometry, synthetic  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
-YML = os.path.join(ROOT, "config_files", "config_4_level_optimization_analytic.yml")
-W, H = 640, 480
+# headline workload (BASELINE.json configs[1] / configs[3]); --workload cfg5 switches to configs[4]'s shape
+WORKLOADS = {
+    "cfg2": dict(yml="config_4_level_optimization_analytic.yml", size=(640, 480),
+                 metric="frame-pair alignments/sec (640x480, 4-level)"),
+    "cfg5": dict(yml="config_6_level_optimization_analytic.yml", size=(1280, 960),
+                 metric="frame-pair alignments/sec (1280x960, 6-level; not the headline metric)"),
+}
 
 
 def parse():
@@ -52,6 +57,9 @@ def parse():
                     help="plane storage (f64 = reference-exact; arithmetic is fp64 in every mode)")
     ap.add_argument("--huber", type=float, default=0.0, help="Huber delta on every level (0 = off)")
     ap.add_argument("--bilinear", action="store_true", help="bilinear forward-additive sampling + corrected Jacobian")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2",
+                    help="cfg2 = the headline 640x480 4-level workload; cfg5 = BASELINE.json configs[4]'s shape "
+                         "(1280x960, config_6_level; combine with --storage f16 --huber 0.05)")
     return ap.parse_args()
 
 
@@ -76,6 +84,9 @@ def run_steps(eng, src, tgt, steps, world, device, n_global):
 
 def main():
     args = parse()
+    wl = WORKLOADS[args.workload]
+    YML = os.path.join(ROOT, "config_files", wl["yml"])
+    W, H = wl["size"]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -244,7 +255,8 @@ def main():
 
     # ---- one pair at a time through the class surface (BASELINE.json configs[1] read literally; never `value`) ----
     single = None
-    if rank == 0 and world == 1 and not args.no_reference_termination and plain_mode and args.storage == "f64":
+    if (rank == 0 and world == 1 and not args.no_reference_termination and plain_mode and args.storage == "f64"
+            and args.workload == "cfg2"):
         single = {}
         with odometry.CPhotoconsistencyOdometryAnalytic(local_rank) as po:
             po.SetIntrinsicMatrix(seq["K"])
@@ -261,7 +273,7 @@ def main():
                     dev_ms.append(po.LastOptimizeMilliseconds())
                 single[name] = dict(device_ms=float(np.median(dev_ms)), host_wall_ms=float(np.median(wall_ms)),
                                     iterations=[int(v) for v in po.GetReport().iterations[:nl]])
-        single["note"] = ("one 640x480 pair per Optimize() call (SetSourceFrame/SetTargetFrame outside the timer, as the "
+        single["note"] = (f"one {W}x{H} pair per Optimize() call (SetSourceFrame/SetTargetFrame outside the timer, as the "
                           "reference's FrameAlignment app times it): latency-bound, one workgroup per level")
 
     # ---- CPU baseline: the oracle, one thread, bounded sample of the same workload ------------
@@ -279,7 +291,7 @@ def main():
             done += 1
             t = (t + 1) % distinct
         cpu = dict(value=done / t_cpu, unit="alignments/s", cores=1, kind="port",
-                   sample=f"{done} alignments over the same synthetic 640x480 pairs, fixed-iteration mode, Optimize() only "
+                   sample=f"{done} alignments over the same synthetic {W}x{H} pairs, fixed-iteration mode, Optimize() only "
                           f"({t_cpu:.1f} s, gcc -O3 -mtune=native, single thread as the reference builds)",
                    host_cpus=os.cpu_count())
 
@@ -312,7 +324,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "frame-pair alignments/sec (640x480, 4-level)",
+            "metric": wl["metric"],
             "value": value,
             "unit": "alignments/s",
             "n_gpus": world,
@@ -325,9 +337,10 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "config_4_level_optimization_analytic.yml on synthetic 640x480 RGB-D, fixed-iteration "
-                            "mode (min_gradient_norm=0: 50 iterations at 80x60 + 20 at 160x120 per pair), "
-                            "Optimize() only with pyramids resident in HBM",
+                "workload": f"{wl['yml']} on synthetic {W}x{H} RGB-D, fixed-iteration mode (min_gradient_norm=0: "
+                            + " + ".join(f"{max_iter[l]} iterations at {eng.level_size(l)[0]}x{eng.level_size(l)[1]}"
+                                         for l in range(nl - 1, -1, -1) if max_iter[l] > 0)
+                            + " per pair), Optimize() only with pyramids resident in HBM",
                 "pairs_per_gpu": n_local, "global_pairs_per_step": n_global,
                 "distinct_pairs_per_gpu": distinct, "image": [W, H], "levels": nl,
                 "max_num_iterations": max_iter, "parallelism": f"pairs sharded x{world}, RCCL all_gather of states",

@@ -77,6 +77,7 @@ struct phovo_engine {
   phovo_pair_report *d_reports = nullptr;
   int *d_owner = nullptr;
   size_t owner_capacity = 0;
+  bool owner_tagged = false;                   // d_owner holds tagged entries of the persistent kernel, not the -1 the wide form expects
   int *d_work_counters = nullptr;              // [PHOVO_MAX_LEVELS] pair counters of the persistent kernels' work queues
   int cu_count = 256;
   void *d_wide_ws = nullptr;                   // workspace of the wide (many-workgroups-per-pair) level form
@@ -771,7 +772,8 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
     if (e->d_owner) { PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream)); (void)hipFree(e->d_owner); e->d_owner = nullptr; e->owner_capacity = 0; }
     PHOVO_HIP_CHECK(hipMalloc(&e->d_owner, sizeof(int) * owner_need));
     e->owner_capacity = owner_need;
-    // -1 everywhere once; pass 2 of the kernel restores -1 after every iteration
+    e->owner_tagged = false;
+    // -1 everywhere once: the wide form restores -1 after every iteration, the persistent kernel wipes per pair
     PHOVO_HIP_CHECK(fill_i32(e->d_owner, owner_need, -1, e->stream));
   }
 
@@ -824,10 +826,16 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
     PHOVO_HIP_CHECK(hipEventRecord(e->ev_start[l], e->stream));
     if (e->ext.sampling == PHOVO_SAMPLING_BILINEAR)
       PHOVO_HIP_CHECK(gn_launch_level_bilinear(a, e->ext.plane_storage, e->ext.jacobian_corrected != 0, e->cu_count, e->stream));
-    else if (use_wide_level(e, n_pairs, lv.n) && !(e->ext.huber_delta[l] > 0.0))
+    else if (use_wide_level(e, n_pairs, lv.n) && !(e->ext.huber_delta[l] > 0.0)) {
+      if (e->owner_tagged) {            // the wide form starts from -1 everywhere and leaves it so
+        PHOVO_HIP_CHECK(fill_i32(e->d_owner, e->owner_capacity, -1, e->stream));
+        e->owner_tagged = false;
+      }
       PHOVO_HIP_CHECK(gn_run_level_wide(a, n_pairs, e->d_wide_ws, e->h_wide_done.data(), e->stream));
-    else
+    } else {
       PHOVO_HIP_CHECK(gn_launch_level(a, lv.plan, e->ext.plane_storage, e->cu_count, e->stream));
+      if (!lv.plan.owner_in_lds) e->owner_tagged = true;     // tagged entries stay behind (the kernel wipes per pair)
+    }
     PHOVO_HIP_CHECK(hipEventRecord(e->ev_stop[l], e->stream));
     e->level_launched[l] = true;
   }

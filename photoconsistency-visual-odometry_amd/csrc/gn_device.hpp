@@ -204,6 +204,13 @@ __device__ __forceinline__ double fast_rcp(double x)
   return fma(r, e, r);
 }
 
+// Entries of an owner map kept in HBM: (iteration tag << 21) | source index.  atomicMax still picks the largest
+// source index among the entries of the running iteration, and every entry of an earlier one is smaller than any of
+// them, so the map needs no reset between iterations (it is wiped per pair and whenever the 1023 tags start over).
+constexpr int OWNER_TAG_SHIFT = 21;
+constexpr int OWNER_INDEX_MASK = (1 << OWNER_TAG_SHIFT) - 1;      // levels of up to 2 097 151 pixels
+constexpr int OWNER_TAG_PERIOD = 1023;
+
 // C round() -- half away from zero (...Analytic.h:297-298) -- for arguments > -0.5, which is all the bounds test lets
 // through: trunc, exact fraction, +1 when the fraction reaches one half.  Five instructions; the library round() also
 // carries the sign through (seven).  (-0.5, 0) gives +0 where round() gives -0: both are pixel 0.

@@ -97,7 +97,13 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
   // ---- level prologue -------------------------------------------------------------------
   if (OWNER_LDS) {
     for (int k = tid; k < n; k += T) s_owner[k] = -1;
-  }   // the global owner map is cleared by the host before the launch and re-cleared in pass 2
+  } else {
+    // Owner map in HBM: entries carry the iteration they were written in (OWNER_TAG_SHIFT), so nothing has to be
+    // reset between iterations; it is wiped once per pair here (the barrier below waits for the stores, and the
+    // map is touched by this workgroup only).
+    for (int k = tid; k < n; k += T) g_owner[k] = -1;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  }
   if (SRC_LDS) {
     for (int k = tid; k < n; k += T) s_i0[k] = plane_load<TI>(rI0, k);
   }
@@ -151,6 +157,18 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
     const double t1 = uniform_f64(s_cst[C_T1]), t2 = uniform_f64(s_cst[C_T2]), t3 = uniform_f64(s_cst[C_T3]);
     const double t14 = uniform_f64(s_cst[C_T14]), t15 = uniform_f64(s_cst[C_T15]);
 
+    // Owner map in HBM: this iteration's tag (1..OWNER_TAG_PERIOD); when the tags start over the map is wiped.
+    int owner_tag = 0;
+    if constexpr (!OWNER_LDS) {
+      const int tg = iteration % OWNER_TAG_PERIOD + 1;
+      if (iteration > 0 && tg == 1) {                                     // uniform: every wave takes it
+        for (int kk = tid; kk < n; kk += T) g_owner[kk] = -1;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+      owner_tag = tg << OWNER_TAG_SHIFT;
+    }
+
     // ---- pass 1: warp every source pixel, resolve who owns each target pixel -------------
     // MASK_REG: chunk j's "landed in bounds" ballot lives in lane j of two registers (v_writelane here, v_readlane
     // + exec mask in pass 2): no per-lane shifting and masking in either pass
@@ -165,9 +183,8 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
       // scalar operand, and the rotation entry already is one
       double cxv = cx, cyv = cyy, czv = cz;
       asm volatile("" : "+v"(cxv), "+v"(cyv), "+v"(czv));
-      auto chunk_body = [&](const int chunk) {
-        const double pz = pz_next;                                        // :279
-        pz_next = plane_load<TD>(rD0, k + NW * WAVE);                     // past the plane: 0
+      // warp of one 64-pixel chunk: ballot of "valid and landed in bounds" and the target index of every lane
+      auto warp_chunk = [&](const double pz, unsigned long long &m_out, int &t_out) {
         // No branch around the arithmetic: a lane that fails the depth gate computes on whatever it loaded and is
         // dropped by `valid` below (a whole wave of invalid pixels is rare), and the ballot of a flat condition is
         // the AND of the compare masks -- scalar work only.
@@ -190,29 +207,78 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
             __builtin_amdgcn_ballot_w64(pz < max_d) & __builtin_amdgcn_ballot_w64(tr > -0.5) &
             __builtin_amdgcn_ballot_w64(rr < dH) & __builtin_amdgcn_ballot_w64(tc > -0.5) &
             __builtin_amdgcn_ballot_w64(rc < dW);
-        if (__builtin_amdgcn_inverse_ballot_w64(m)) {
-          const int t = (int)fma(rr, dW, rc);                             // exact in fp64: one fma + one conversion
-          if (OWNER_LDS) atomicMax(&s_owner[t], k);                       // last raster writer wins  :358
-          else atomicMax(&g_owner[t], k);
-        }
+        m_out = m;
+        t_out = (int)fma(rr, dW, rc);                                     // exact in fp64: one fma + one conversion
+      };
+      auto keep_mask = [&](const unsigned long long m, const int chunk) {
         if (MASK_REG) {
           inb_lo = writelane_b32(inb_lo, (int)(unsigned)m, j);
           inb_hi = writelane_b32(inb_hi, (int)(unsigned)(m >> 32), j);
         } else {
           if (lane == 0) s_mask[chunk] = m;
         }
-        k += NW * WAVE;
-        j++;
-        rowcol_advance(cd, rd, rc_step);
       };
-      // two chunks per trip, written out by hand: the ballot / lane accesses are convergent operations, which the
-      // compiler will not duplicate for a run-time trip count (#pragma unroll is refused); the bounds are wave-uniform
-      int chunk = wave;
-      for (; chunk + NW < A.n_chunks; chunk += 2 * NW) {
-        chunk_body(chunk);
-        chunk_body(chunk + NW);
+      if constexpr (OWNER_LDS) {
+        auto chunk_body = [&](const int chunk) {
+          const double pz = pz_next;                                      // :279
+          pz_next = plane_load<TD>(rD0, k + NW * WAVE);                   // past the plane: 0
+          unsigned long long m;
+          int t;
+          warp_chunk(pz, m, t);
+          if (__builtin_amdgcn_inverse_ballot_w64(m)) atomicMax(&s_owner[t], k);     // last raster writer wins  :358
+          keep_mask(m, chunk);
+          k += NW * WAVE;
+          j++;
+          rowcol_advance(cd, rd, rc_step);
+        };
+        // two chunks per trip, written out by hand: the ballot / lane accesses are convergent operations, which the
+        // compiler will not duplicate for a run-time trip count (#pragma unroll is refused); the bounds are wave-uniform
+        int chunk = wave;
+        for (; chunk + NW < A.n_chunks; chunk += 2 * NW) {
+          chunk_body(chunk);
+          chunk_body(chunk + NW);
+        }
+        if (chunk < A.n_chunks) chunk_body(chunk);
+      } else {
+        // Owner map in HBM.  The memory counter of a wave retires in order, so a load issued behind a global atomic
+        // waits for that atomic (about 2800 cycles with every CU issuing them): a loop of load - compute - atomic per
+        // chunk ran at the atomic's latency (1600 cycles per chunk against 740 with the map in LDS).  Here four chunks
+        // go together: their depths were requested a group ago, the next group's are requested first, then the four
+        // are warped, and only then do the four atomics go out.
+        constexpr int G = 4;
+        double pzg[G], pzn[G];
+        int pend_t[G], pend_v[G];
+        unsigned long long pend_m[G];
+        pzg[0] = pz_next;
+#pragma unroll
+        for (int g = 1; g < G; g++) pzg[g] = plane_load<TD>(rD0, k + g * NW * WAVE);
+        int chunk = wave;
+        while (chunk < A.n_chunks) {
+#pragma unroll
+          for (int g = 0; g < G; g++) pzn[g] = plane_load<TD>(rD0, k + (G + g) * NW * WAVE);     // past the plane: 0
+          int count = 0;
+#pragma unroll
+          for (int g = 0; g < G; g++) {
+            if (chunk < A.n_chunks) {                                     // wave-uniform
+              warp_chunk(pzg[g], pend_m[g], pend_t[g]);
+              pend_v[g] = owner_tag | k;
+              keep_mask(pend_m[g], chunk);
+              count = g + 1;
+              chunk += NW;
+              k += NW * WAVE;
+              j++;
+              rowcol_advance(cd, rd, rc_step);
+            }
+          }
+#pragma unroll
+          for (int g = 0; g < G; g++) {
+            if (g < count && __builtin_amdgcn_inverse_ballot_w64(pend_m[g]))
+              atomicMax(&g_owner[pend_t[g]], pend_v[g]);                  // last raster writer of THIS iteration wins  :358
+          }
+#pragma unroll
+          for (int g = 0; g < G; g++) pzg[g] = pzn[g];
+        }
       }
-      if (chunk < A.n_chunks) chunk_body(chunk);
     }
     PHOVO_STAMP(0)
     __syncthreads();
@@ -239,16 +305,25 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
       // gathered source intensity right behind them) before this chunk's arithmetic starts.
       int o_n = -1;
       double pz_n = 0.0, gx_n = 0.0, gy_n = 0.0, i1_n = 0.0, i0_n = 0.0;
+      // Owner map in HBM: the entry is requested TWO chunks ahead (o_raw), so that the gather of the source
+      // intensity one chunk ahead starts from an index that has already arrived instead of stalling on it; entries
+      // of earlier iterations fail the tag comparison, so nothing is written back (a store per chunk would hold up
+      // every later load of the wave: the memory counter retires in order).
+      int o_raw = -1;
+      auto owner_request = [&](int kk) {
+        o_raw = kk < n ? __hip_atomic_load(&g_owner[kk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+      };
+      if (!OWNER_LDS) owner_request(k);
       auto fetch = [&](int kk) {
         o_n = -1;
-        if (kk < n) {
-          if (OWNER_LDS) {
+        if (OWNER_LDS) {
+          if (kk < n) {
             o_n = s_owner[kk];
             s_owner[kk] = -1;                       // ready for the next iteration
-          } else {
-            o_n = __hip_atomic_load(&g_owner[kk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&g_owner[kk], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
+        } else {
+          o_n = (o_raw & ~OWNER_INDEX_MASK) == owner_tag ? (o_raw & OWNER_INDEX_MASK) : -1;
+          owner_request(kk + NW * WAVE);
         }
         pz_n = plane_load<TD>(rD0, kk);
         gx_n = plane_load<TI>(rGX, kk);             // gradient at the SOURCE index  :346-347
@@ -585,6 +660,8 @@ size_t lds_fixed_bytes(int threads)
   return sizeof(double) * (32 + 8 + (size_t)nw * NRED) + sizeof(int) * CTL_COUNT;
 }
 
+static_assert((1 << OWNER_TAG_SHIFT) - 1 == OWNER_INDEX_MASK, "index mask and tag shift belong together");
+
 // The instantiations that exist (each one is a separate kernel in the code object):
 //   MID    512 threads, 2 workgroups/CU, owner map in LDS, register mask
 //   WIDE   1024 threads, 1 workgroup/CU, owner map in LDS (80..160 KB), register mask
@@ -637,6 +714,7 @@ bool gn_plan_level(int n, GNLaunchPlan *plan)
   }
   const size_t mask = sizeof(unsigned long long) * n_chunks;
   if (f1024 + mask > LDS_LIMIT) return false;
+  if (n > OWNER_INDEX_MASK) return false;          // the tagged entries of the HBM owner map hold 21-bit indices
   plan->variant = V_HUGE; plan->threads = 1024; plan->wgs_per_cu = 1; plan->owner_in_lds = false; plan->source_in_lds = false;
   plan->lds_bytes = (int)(f1024 + mask);
   return true;

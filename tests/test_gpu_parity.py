@@ -218,6 +218,39 @@ def test_large_level_uses_global_owner_map_and_matches_oracle():
     assert np.array_equal(s1[0], s2[0]) and np.array_equal(s2[0], s2[1])
 
 
+def test_hbm_owner_map_tags_survive_wraparound_and_form_changes():
+    """Levels too large for an owner map in LDS keep it in HBM with entries tagged by iteration (no reset between
+    iterations; 1023 tags, then the map is wiped and the tags start over).  1040 fixed iterations cross the wrap; the
+    many-workgroups form (<= 32 pairs), which shares the buffer and expects -1 everywhere, runs before and after."""
+    w, h = 320, 240
+    p = synthetic.make_pair(31, w, h, holes=0.02, trans=0.01, rot=0.005)
+    ncfg, ocfg = _cfgs(1, [1040], [0.0])
+    es, eits = oracle.align_frames(ocfg, p["K"], p["gray0"], p["depth0"], p["gray1"])
+    short_n, short_o = _cfgs(1, [6], [0.0])
+    es6, eits6 = oracle.align_frames(short_o, p["K"], p["gray0"], p["depth0"], p["gray1"])
+    with odometry.AlignmentEngine() as eng:
+        eng.set_intrinsic_matrix(p["K"])
+        eng.set_config(short_n)
+        eng.reserve_frames(2, w, h)
+        assert not eng.level_launch_info(0)["owner_in_lds"]
+        eng.upload_frame(0, p["gray0"], p["depth0"], roles=native.ROLE_SOURCE)
+        eng.upload_frame(1, p["gray1"], None, roles=native.ROLE_TARGET)
+        assert eng.level_uses_wide(0, 2) and not eng.level_uses_wide(0, 40)
+        a, ra = eng.align_pairs([0] * 2, [1] * 2, want_reports=True)           # wide form: owner buffer at -1
+        b, rb = eng.align_pairs([0] * 40, [1] * 40, want_reports=True)         # persistent form: leaves tagged entries
+        c, rc = eng.align_pairs([0] * 2, [1] * 2, want_reports=True)           # wide form again: must start from -1
+        eng.set_config(ncfg)
+        d, rd = eng.align_pairs([0] * 40, [1] * 40, want_reports=True)         # crosses the tag wrap at iteration 1023
+    for s_, r_ in ((a, ra), (b, rb), (c, rc)):
+        assert list(r_[0].iterations[:1]) == eits6
+        assert se3.state_distance(s_[0], es6) < POSE_TOL
+    assert np.array_equal(a, c)
+    assert all(np.array_equal(b[0], b[i]) for i in range(40))
+    assert list(rd[0].iterations[:1]) == eits == [1040]
+    assert se3.state_distance(d[0], es) < POSE_TOL
+    assert all(np.array_equal(d[0], d[i]) for i in range(40))
+
+
 # ---------------------------------------------------------------------------------------------
 # size-independent properties at full size
 # ---------------------------------------------------------------------------------------------
