@@ -67,13 +67,20 @@ __global__ __launch_bounds__(WT) void k_wide_pass1(const GNLevelArgs A, const do
   int *g_owner = A.g_owner + (size_t)pair * (size_t)n;
   const double fx = A.fx, fy = A.fy, ox = A.ox, oy = A.oy, ifx = A.ifx, ify = A.ify;
   const double min_d = A.min_depth, max_d = A.max_depth, dW = (double)W, dH = (double)H;
-#pragma unroll 2
-  for (int j = 0; j < TILE_CHUNKS / WNW; j++) {
+  // The four depths of this wave are requested before anything else: a wave's memory counter retires in order, so a
+  // load issued behind one of the global atomics below would wait for that atomic.
+  constexpr int CPW = TILE_CHUNKS / WNW;      // chunks per wave
+  double pzs[CPW];
+#pragma unroll
+  for (int j = 0; j < CPW; j++)
+    pzs[j] = plane_load<double>(rD0, (blockIdx.x * TILE_CHUNKS + j * WNW + wave) * WAVE + lane);   // past the plane: 0
+#pragma unroll
+  for (int j = 0; j < CPW; j++) {
     const int chunk = blockIdx.x * TILE_CHUNKS + j * WNW + wave;
     if (chunk >= A.n_chunks) break;
     const int k = chunk * WAVE + lane;
     bool inb = false;
-    const double pz = plane_load<double>(rD0, k);                         // :279 (past the plane: 0)
+    const double pz = pzs[j];                                             // :279
     if (k < n && min_d < pz && pz < max_d) {                              // :280
       const int r = k / W, c = k - r * W;
       const double px = ((double)c - ox) * pz * ifx;                      // :282
@@ -119,20 +126,46 @@ __global__ __launch_bounds__(WT) void k_wide_pass2(const GNLevelArgs A, const do
   double acc[NRED];
 #pragma unroll
   for (int j = 0; j < NRED; j++) acc[j] = 0.0;
-  for (int j = 0; j < TILE_CHUNKS / WNW; j++) {
+  // Every load of the wave's four chunks goes out first -- owners, then the planes, then the gathers that need the
+  // owners -- and the owner slots are reset only after the last load has been issued: issued in between, each store and
+  // each dependent gather would hold up everything behind it (the memory counter retires in order).
+  constexpr int CPW = TILE_CHUNKS / WNW;      // chunks per wave
+  int os[CPW];
+  unsigned long long ms[CPW];
+  double pzs[CPW], gxs[CPW], gys[CPW], i1s[CPW], i0s[CPW];
+#pragma unroll
+  for (int j = 0; j < CPW; j++) {
+    const int chunk = blockIdx.x * TILE_CHUNKS + j * WNW + wave;
+    const int k = chunk * WAVE + lane;
+    os[j] = k < n ? g_owner[k] : -1;
+    ms[j] = chunk < A.n_chunks ? g_mask[(size_t)pair * A.n_chunks + chunk] : 0ull;
+  }
+#pragma unroll
+  for (int j = 0; j < CPW; j++) {
+    const int k = (blockIdx.x * TILE_CHUNKS + j * WNW + wave) * WAVE + lane;
+    pzs[j] = plane_load<double>(rD0, k);                                  // past the plane: 0
+    gxs[j] = plane_load<double>(rGX, k);                                  // gradient at the SOURCE index  :346-347
+    gys[j] = plane_load<double>(rGY, k);
+    i1s[j] = plane_load<double>(rI1, k);                                  // :309
+  }
+#pragma unroll
+  for (int j = 0; j < CPW; j++) i0s[j] = plane_load<double>(rI0, os[j]);  // :308 (owner -1: past the plane -> 0)
+#pragma unroll
+  for (int j = 0; j < CPW; j++) {                 // every slot is read once and made ready for the next pass 1
+    const int k = (blockIdx.x * TILE_CHUNKS + j * WNW + wave) * WAVE + lane;
+    if (k < n) g_owner[k] = -1;
+  }
+#pragma unroll
+  for (int j = 0; j < CPW; j++) {
     const int chunk = blockIdx.x * TILE_CHUNKS + j * WNW + wave;
     if (chunk >= A.n_chunks) break;
     const int k = chunk * WAVE + lane;
-    int o = -1;
-    if (k < n) {                                  // this pixel's slot is read once and made ready for the next pass 1
-      o = g_owner[k];
-      g_owner[k] = -1;
-    }
-    const unsigned long long m = g_mask[(size_t)pair * A.n_chunks + chunk];
+    const int o = os[j];
+    const unsigned long long m = ms[j];
     if (!((m >> lane) & 1ull)) continue;
-    const double pz = plane_load<double>(rD0, k);
-    const double gxi = plane_load<double>(rGX, k), gyi = plane_load<double>(rGY, k);   // gradient at the SOURCE index  :346-347
-    const double res = o >= 0 ? plane_load<double>(rI1, k) - plane_load<double>(rI0, o) : 0.0;   // :308-309,358
+    const double pz = pzs[j];
+    const double gxi = gxs[j], gyi = gys[j];
+    const double res = o >= 0 ? i1s[j] - i0s[j] : 0.0;                    // :308-309,358
     const int r = k / W, c = k - r * W;
     const double px = ((double)c - ox) * pz * ifx;
     const double py = ((double)r - oy) * pz * ify;
