@@ -55,10 +55,17 @@ def gather_states(local_states, n_pairs_total, device=None, group=None):
     if t.shape[0] != b - a:
         raise ValueError(f"rank {rank} holds {t.shape[0]} pairs, its shard has {b - a}")
     pad[: b - a] = t.reshape(-1, 6)
-    out = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(out, pad, group=group)
-    parts = [o[: (sb - sa)].cpu().numpy() for o, (sa, sb) in zip(out, sizes)]
-    return np.concatenate(parts, axis=0)
+    # one collective into one tensor and ONE copy back to the host (eight small device-to-host copies per step would
+    # cost more than the all_gather itself)
+    big = torch.empty((world, max_p, 6), dtype=torch.float64, device=t.device)
+    try:
+        dist.all_gather_into_tensor(big, pad, group=group)
+    except (RuntimeError, NotImplementedError, AttributeError):      # a backend without the tensor form
+        out = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(out, pad, group=group)
+        big = torch.stack(out)
+    host = big.cpu().numpy()
+    return np.concatenate([host[r, : (sb - sa)] for r, (sa, sb) in enumerate(sizes)], axis=0)
 
 
 def trajectory_from_states(states):
