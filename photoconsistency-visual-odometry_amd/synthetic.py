@@ -30,7 +30,7 @@ class Scene:
     """Textured plane n.p = d in the frame of camera 0, texture = sum of 12 sinusoids."""
 
     def __init__(self, seed, n_terms=12):
-        rs = np.random.RandomState(seed)
+        rs = np.random.RandomState((seed) % (2 ** 32))
         n = np.array([0.1, -0.05, 1.0])
         self.n = n / np.linalg.norm(n)
         self.d = 2.0
@@ -67,7 +67,7 @@ def render(scene, T_c0, width, height, K=None, holes=0.0, hole_seed=0):
     gray = np.rint(255.0 * scene.texture(P0[..., 0], P0[..., 1])).astype(np.uint8)
     depth = np.rint(Z * 1000.0) / 1000.0
     if holes > 0:
-        rs = np.random.RandomState(hole_seed)
+        rs = np.random.RandomState((hole_seed) % (2 ** 32))
         depth = np.where(rs.uniform(size=depth.shape) < holes, 0.0, depth)
     return gray, depth
 
@@ -80,7 +80,7 @@ def make_pair(seed, width=640, height=480, holes=0.0, trans=0.03, rot=0.015):
     """One frame pair.  Returns dict(gray0, depth0, gray1, depth1, K, motion) where
     `motion` is the state vector (x,y,z,yaw,pitch,roll) of T_10, i.e. what Optimize()
     is expected to approach."""
-    rs = np.random.RandomState(1000003 * seed + 17)
+    rs = np.random.RandomState((1000003 * seed + 17) % (2 ** 32))
     scene = Scene(seed)
     m = random_motion(rs, trans, rot)
     K = intrinsics(width, height)
@@ -95,7 +95,7 @@ def make_sequence(seed, n_frames, width=640, height=480, holes=0.0, trans=0.02, 
     Returns dict(gray [F,H,W] u8, depth [F,H,W] f64, K, poses [F,4,4] (T_t0),
     motions [F-1,4,4] where motions[t] = T_{t+1,0} . T_{t,0}^-1 is the ground truth
     of pair (t, t+1))."""
-    rs = np.random.RandomState(7919 * seed + 3)
+    rs = np.random.RandomState((7919 * seed + 3) % (2 ** 32))
     scene = Scene(seed)
     K = intrinsics(width, height)
     T = np.eye(4)
