@@ -68,15 +68,23 @@ def algorithmic_bytes(level_sizes, iterations):
     return sum(5.0 * 8.0 * n * it for n, it in zip(level_sizes, iterations))
 
 
-def run_steps(eng, src, tgt, steps, world, device, n_global):
+def run_steps(eng, src, tgt, steps, use_dist, device, n_global):
     """Runs `steps` steps; returns (wall seconds of this rank, per-level kernel ms summed over the steps)."""
     per_level = np.zeros(native.MAX_LEVELS)
     t0 = time.perf_counter()
     for _ in range(steps):
         eng.enqueue_align(src, tgt)
         eng.synchronize()
-        if world > 1:
-            distributed.gather_states(eng.fetch_results(len(src)), n_global, device=device)
+        if use_dist:
+            local = None
+            if device.type == "cuda":        # RCCL: start the collective from the engine's own device buffer
+                try:
+                    local = distributed.device_states_tensor(eng.results_device_ptr(), len(src), device)
+                except Exception:             # no __cuda_array_interface__ support: go through the host
+                    local = None
+            if local is None:
+                local = eng.fetch_results(len(src))
+            distributed.gather_states(local, n_global, device=device)
         _, lv = eng.last_align_ms()
         per_level += np.array(lv)
     return time.perf_counter() - t0, per_level
@@ -91,7 +99,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch = dist = device = None
-    if world > 1 or args.gpus > 1:
+    # PHOVO_BENCH_FORCE_DIST=1: initialise torch.distributed even for one rank (rehearses the RCCL code path --
+    # init, barrier, all_reduce, all_gather -- on a one-GPU box; launch with torch.distributed.run --nproc-per-node 1)
+    force_dist = os.environ.get("PHOVO_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
+    if world > 1 or args.gpus > 1 or force_dist:
         import torch
         import torch.distributed as dist
         if world != args.gpus:
@@ -109,6 +120,7 @@ def main():
             device = torch.device("cpu")
             dist.init_process_group(backend)
 
+    use_dist = dist is not None
     if native.lib().phovo_device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: the alignment path has no CPU fallback")
 
@@ -150,18 +162,18 @@ def main():
     launch = {l: eng.level_launch_info(l) for l in range(nl) if max_iter[l] > 0}
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
             if device.type == "cuda":
                 torch.cuda.synchronize()
         eng.synchronize()
 
     # ---- timed region: fixed-iteration mode ---------------------------------------------------
-    run_steps(eng, src, tgt, args.warmup, world, device, n_global)
+    run_steps(eng, src, tgt, args.warmup, use_dist, device, n_global)
     barrier()
-    wall, per_level_ms = run_steps(eng, src, tgt, args.steps, world, device, n_global)
+    wall, per_level_ms = run_steps(eng, src, tgt, args.steps, use_dist, device, n_global)
     barrier()
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([wall], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         wall = float(tmax.item())
@@ -214,12 +226,12 @@ def main():
     ref_term = None
     if not args.no_reference_termination:
         eng.set_config(cfg_ref)
-        run_steps(eng, src, tgt, 1, world, device, n_global)
+        run_steps(eng, src, tgt, 1, use_dist, device, n_global)
         barrier()
         k2 = max(2, args.steps // 2)
-        wall2, _ = run_steps(eng, src, tgt, k2, world, device, n_global)
+        wall2, _ = run_steps(eng, src, tgt, k2, use_dist, device, n_global)
         barrier()
-        if world > 1:
+        if use_dist:
             tmax = torch.tensor([wall2], dtype=torch.float64, device=device)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             wall2 = float(tmax.item())
@@ -362,7 +374,7 @@ def main():
         }
         print(json.dumps(out))
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

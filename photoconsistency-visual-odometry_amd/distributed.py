@@ -30,6 +30,23 @@ def frames_needed(pair_start, pair_stop):
     return pair_start, pair_stop + 1
 
 
+class _DeviceBuffer:
+    """A [n, 6] fp64 array that already lives on the GPU (the engine's result buffer), described the way
+    torch.as_tensor understands (__cuda_array_interface__), so that the collective can start from it without a trip
+    through host memory."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n), 6), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def device_states_tensor(ptr, n, device):
+    """Zero-copy torch view of the engine's device-resident states (phovo_engine_results_device_ptr).  The engine's
+    stream must have been synchronised; the view is valid until the next enqueue."""
+    import torch
+    return torch.as_tensor(_DeviceBuffer(ptr, n), device=device)
+
+
 def gather_states(local_states, n_pairs_total, device=None, group=None):
     """all_gather of the per-rank [p_r, 6] state blocks -> [n_pairs_total, 6] on every rank.
 
@@ -46,7 +63,7 @@ def gather_states(local_states, n_pairs_total, device=None, group=None):
             t = t.to(device)
     else:
         t = local_states
-    if world == 1:
+    if not dist.is_initialized():
         return t.detach().cpu().numpy().reshape(-1, 6)[:n_pairs_total]
     sizes = [shard_range(n_pairs_total, world, r) for r in range(world)]
     max_p = max(b - a for a, b in sizes)

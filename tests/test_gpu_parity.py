@@ -564,3 +564,24 @@ def test_randomised_sweep_against_oracle():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "80 cases, 0 failures" in r.stdout
+
+
+def test_device_result_buffer_as_torch_tensor(vga_pairs):
+    """bench.py --gpus N starts its all_gather from the engine's device buffer: the zero-copy torch view of
+    phovo_engine_results_device_ptr must hold exactly what fetch_results copies out."""
+    torch = pytest.importorskip("torch")
+    from phovo_amd import distributed
+    ncfg, _ = _cfgs(4, [0, 0, 3, 3], [0.0] * 4)
+    p = vga_pairs[0]
+    with odometry.AlignmentEngine() as eng:
+        eng.set_config(ncfg)
+        eng.set_intrinsic_matrix(p["K"])
+        eng.reserve_frames(2, 640, 480)
+        eng.upload_frame(0, p["gray0"], p["depth0"], roles=native.ROLE_SOURCE)
+        eng.upload_frame(1, p["gray1"], None, roles=native.ROLE_TARGET)
+        eng.enqueue_align([0] * 5, [1] * 5)
+        eng.synchronize()
+        host = eng.fetch_results(5)
+        t = distributed.device_states_tensor(eng.results_device_ptr(), 5, torch.device("cuda", 0))
+        assert t.is_cuda and tuple(t.shape) == (5, 6) and t.dtype == torch.float64
+        assert np.array_equal(t.cpu().numpy(), host)
