@@ -146,8 +146,15 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
   unsigned long long st_prev = clock64();
   const unsigned long long st_begin = wall_clock64();       // 100 MHz, common to all CUs: when this pair's first iteration began
 #define PHOVO_STAMP(i) { unsigned long long _n = clock64(); st_sum[i] += _n - st_prev; st_prev = _n; }
+  // the serial section of wave 0 in three parts: cross-wave sum + broadcast, solve + update, pose constants
+  unsigned long long st_sub[3] = {0, 0, 0};
+  unsigned long long st_sub_prev = 0;
+#define PHOVO_SUBSTAMP_BEGIN { st_sub_prev = clock64(); }
+#define PHOVO_SUBSTAMP(i) { unsigned long long _n = clock64(); st_sub[i] += _n - st_sub_prev; st_sub_prev = _n; }
 #else
 #define PHOVO_STAMP(i)
+#define PHOVO_SUBSTAMP_BEGIN
+#define PHOVO_SUBSTAMP(i)
 #endif
   while (true) {
     // ---- constants of this iteration (uniform -> SGPRs) -----------------------------------
@@ -424,6 +431,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
 
     // ---- wave 0: cross-wave sum (fixed order), solve, update, terminate ------------------------
     if (wave == 0) {
+      PHOVO_SUBSTAMP_BEGIN
       // lane l sums value (l & 31) over half of the waves, the halves meet in one shuffle
       double v = 0.0;
       {
@@ -439,6 +447,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
 #pragma unroll
       for (int i = 0; i < 6; i++) g[i] = __shfl(v, 21 + i, WAVE);
 
+      PHOVO_SUBSTAMP(0)
       double step[6];
       solve6_ldlt(h, g, step);
       double st[6];
@@ -457,7 +466,9 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
       if (it >= A.max_iter) done = true;                                                // :383
       else if (gnorm < A.min_grad_norm) done = true;                                    // :388
       if (!finite) done = true;     // the reference would keep iterating on NaN; the result is the same NaN
+      PHOVO_SUBSTAMP(1)
       if (!done) write_pose_constants(st[0], st[1], st[2], st[3], st[4], st[5], s_cst, lane);   // wave-uniform branch
+      PHOVO_SUBSTAMP(2)
       if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < 6; i++) s_state[i] = st[i];
@@ -484,6 +495,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
       // diagnostic build only: phase cycle sums of wave 0 go to the otherwise unused report slots 8..12
       for (int j = 0; j < 5; j++) A.reports[pair].iterations[8 + j] = (int)(st_sum[j] / (unsigned long long)iteration);
       // slots 13..15 (last level launched wins): begin / end of the pair on the 100 MHz wall clock, and the workgroup
+      for (int j = 0; j < 3; j++) A.reports[pair].iterations[5 + j] = (int)(st_sub[j] / (unsigned long long)iteration);
       A.reports[pair].iterations[13] = (int)(unsigned)st_begin;
       A.reports[pair].iterations[14] = (int)(unsigned)wall_clock64();
       A.reports[pair].iterations[15] = (int)blockIdx.x;

@@ -566,22 +566,36 @@ def test_randomised_sweep_against_oracle():
     assert "80 cases, 0 failures" in r.stdout
 
 
-def test_device_result_buffer_as_torch_tensor(vga_pairs):
+def test_device_result_buffer_as_torch_tensor():
     """bench.py --gpus N starts its all_gather from the engine's device buffer: the zero-copy torch view of
-    phovo_engine_results_device_ptr must hold exactly what fetch_results copies out."""
-    torch = pytest.importorskip("torch")
-    from phovo_amd import distributed
-    ncfg, _ = _cfgs(4, [0, 0, 3, 3], [0.0] * 4)
-    p = vga_pairs[0]
-    with odometry.AlignmentEngine() as eng:
-        eng.set_config(ncfg)
-        eng.set_intrinsic_matrix(p["K"])
-        eng.reserve_frames(2, 640, 480)
-        eng.upload_frame(0, p["gray0"], p["depth0"], roles=native.ROLE_SOURCE)
-        eng.upload_frame(1, p["gray1"], None, roles=native.ROLE_TARGET)
-        eng.enqueue_align([0] * 5, [1] * 5)
-        eng.synchronize()
-        host = eng.fetch_results(5)
-        t = distributed.device_states_tensor(eng.results_device_ptr(), 5, torch.device("cuda", 0))
-        assert t.is_cuda and tuple(t.shape) == (5, 6) and t.dtype == torch.float64
-        assert np.array_equal(t.cpu().numpy(), host)
+    phovo_engine_results_device_ptr must hold exactly what fetch_results copies out.  Run in a fresh process with
+    torch initialised first, as bench.py does (torch brings its own HIP runtime; the library uses the system's)."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np
+import torch
+if not torch.cuda.is_available():
+    print("SKIP"); sys.exit(0)
+torch.cuda.set_device(0)
+sys.path.insert(0, %r)
+import phovo_amd
+from phovo_amd import native, odometry, synthetic, distributed
+p = synthetic.make_pair(0, 640, 480)
+cfg = native.make_config(num_levels=4, max_iter=[0, 0, 3, 3], min_grad=[0.0] * 4)
+with odometry.AlignmentEngine() as eng:
+    eng.set_config(cfg); eng.set_intrinsic_matrix(p["K"]); eng.reserve_frames(2, 640, 480)
+    eng.upload_frame(0, p["gray0"], p["depth0"], roles=native.ROLE_SOURCE)
+    eng.upload_frame(1, p["gray1"], None, roles=native.ROLE_TARGET)
+    eng.enqueue_align([0] * 5, [1] * 5); eng.synchronize()
+    host = eng.fetch_results(5)
+    t = distributed.device_states_tensor(eng.results_device_ptr(), 5, torch.device("cuda", 0))
+    assert t.is_cuda and tuple(t.shape) == (5, 6) and t.dtype == torch.float64
+    assert np.array_equal(t.cpu().numpy(), host) and np.all(np.isfinite(host)) and np.any(host != 0)
+print("OK")
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    if "SKIP" in r.stdout:
+        pytest.skip("torch sees no GPU in a fresh process")
+    assert "OK" in r.stdout

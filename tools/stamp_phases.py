@@ -43,3 +43,5 @@ for levels in ([0, 0, 20, 0], [0, 0, 0, 50]):
         print(f"levels {levels}: kernel {ms:.3f} ms for {len(src)} pairs; cycles/iteration {tot:.0f}")
         for j, nme in enumerate(names):
             print(f"   {nme:16s} {st[:, j].mean():9.0f} cycles  {100 * st[:, j].mean() / tot:5.1f} %")
+        sub = np.array([[r.iterations[5 + j] for j in range(3)] for r in reps_], dtype=np.float64).mean(axis=0)
+        print(f"   serial section of wave 0: sum+broadcast {sub[0]:.0f}, solve+update {sub[1]:.0f}, pose constants {sub[2]:.0f} cycles")
