@@ -68,6 +68,24 @@ def algorithmic_bytes(level_sizes, iterations):
     return sum(5.0 * 8.0 * n * it for n, it in zip(level_sizes, iterations))
 
 
+ZERO_COPY = {"ok": None}      # None = not probed yet; decided once by probe_zero_copy() outside the timed region
+
+
+def probe_zero_copy(eng, n_local, device):
+    """May the all_gather start from the engine's device buffer?  torch brings its own HIP runtime and the library
+    uses the system's, so this is checked once, after the warm-up steps: the torch view of the device pointer must
+    read back exactly what the library's own copy returns; anything else (or any exception) selects the host path."""
+    ZERO_COPY["ok"] = False
+    if device is None or device.type != "cuda":
+        return
+    try:
+        host = eng.fetch_results(n_local)
+        view = distributed.device_states_tensor(eng.results_device_ptr(), n_local, device)
+        ZERO_COPY["ok"] = bool(view.device == device and np.array_equal(view.cpu().numpy(), host))
+    except Exception:
+        ZERO_COPY["ok"] = False
+
+
 def run_steps(eng, src, tgt, steps, use_dist, device, n_global):
     """Runs `steps` steps; returns (wall seconds of this rank, per-level kernel ms summed over the steps)."""
     per_level = np.zeros(native.MAX_LEVELS)
@@ -76,13 +94,9 @@ def run_steps(eng, src, tgt, steps, use_dist, device, n_global):
         eng.enqueue_align(src, tgt)
         eng.synchronize()
         if use_dist:
-            local = None
-            if device.type == "cuda":        # RCCL: start the collective from the engine's own device buffer
-                try:
-                    local = distributed.device_states_tensor(eng.results_device_ptr(), len(src), device)
-                except Exception:             # no __cuda_array_interface__ support: go through the host
-                    local = None
-            if local is None:
+            if ZERO_COPY["ok"]:               # RCCL: start the collective from the engine's own device buffer
+                local = distributed.device_states_tensor(eng.results_device_ptr(), len(src), device)
+            else:
                 local = eng.fetch_results(len(src))
             distributed.gather_states(local, n_global, device=device)
         _, lv = eng.last_align_ms()
@@ -102,7 +116,13 @@ def main():
     # PHOVO_BENCH_FORCE_DIST=1: initialise torch.distributed even for one rank (rehearses the RCCL code path --
     # init, barrier, all_reduce, all_gather -- on a one-GPU box; launch with torch.distributed.run --nproc-per-node 1)
     force_dist = os.environ.get("PHOVO_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
+    saved_stdout = None
     if world > 1 or args.gpus > 1 or force_dist:
+        # RCCL prints its version banner on stdout when the first communicator is made; stdout carries ONE JSON line,
+        # so everything the native libraries write there goes to stderr until that line is printed.
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         import torch
         import torch.distributed as dist
         if world != args.gpus:
@@ -170,6 +190,10 @@ def main():
 
     # ---- timed region: fixed-iteration mode ---------------------------------------------------
     run_steps(eng, src, tgt, args.warmup, use_dist, device, n_global)
+    if use_dist:
+        if args.warmup == 0:
+            run_steps(eng, src, tgt, 1, False, device, n_global)       # something to compare
+        probe_zero_copy(eng, n_local, device)
     barrier()
     wall, per_level_ms = run_steps(eng, src, tgt, args.steps, use_dist, device, n_global)
     barrier()
@@ -356,6 +380,7 @@ def main():
                 "pairs_per_gpu": n_local, "global_pairs_per_step": n_global,
                 "distinct_pairs_per_gpu": distinct, "image": [W, H], "levels": nl,
                 "max_num_iterations": max_iter, "parallelism": f"pairs sharded x{world}, RCCL all_gather of states",
+                "all_gather_from_device_buffer": ZERO_COPY["ok"],
             },
             "iterations_per_pair": [float(x) for x in iters.mean(axis=0)],
             "nonfinite_pairs": nonfinite,
@@ -372,7 +397,12 @@ def main():
             "end_to_end_pcie_inclusive": e2e,
             "single_pair": single,
         }
-        print(json.dumps(out))
+        sys.stdout.flush()
+        if saved_stdout is not None:
+            os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
+        if saved_stdout is not None:
+            os.dup2(2, 1)
     eng.close()
     if use_dist:
         dist.destroy_process_group()
