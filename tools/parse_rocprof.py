@@ -1,6 +1,6 @@
 """Turns the rocprofv3 outputs of one profiling session into the files kept under profiles/:
 
-    python tools/parse_rocprof.py gpurun_out/prof_r01 profiles r01 [--current] [--pairs 2048]
+    python tools/parse_rocprof.py gpurun_out/prof_r01 profiles r01 [--current] [--pairs 8192]
 
 --pairs is the number of frame pairs each profiled launch aligned (bench.py --pairs): the level kernels draw pairs
 from a work queue, so the grid size no longer says how many there were.
@@ -76,7 +76,7 @@ def sq_summary(rows, pairs):
 
 def main():
     src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
-    pairs = int(sys.argv[sys.argv.index("--pairs") + 1]) if "--pairs" in sys.argv else 2048
+    pairs = int(sys.argv[sys.argv.index("--pairs") + 1]) if "--pairs" in sys.argv else 8192
     os.makedirs(dst, exist_ok=True)
     for f in glob.glob(os.path.join(src, "stats", "**", "*_kernel_stats.csv"), recursive=True):
         shutil.copy(f, os.path.join(dst, f"{tag}_kernel_stats.csv"))
