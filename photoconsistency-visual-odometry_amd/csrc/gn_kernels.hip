@@ -565,6 +565,8 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel_bilinear(const GNLevel
   const int k0 = wave * WAVE + lane;
   const int r0 = k0 / W, c0 = k0 - r0 * W;
   const int step_r = (NW * WAVE) / W, step_c = (NW * WAVE) - step_r * W;
+  const RowColStep rc_step = make_rowcol_step(step_r, step_c, W);
+  const double cd0 = (double)c0, rd0 = (double)r0;
 
   int iteration = 0;
   double last_gnorm = 0.0;
@@ -583,67 +585,119 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel_bilinear(const GNLevel
 #pragma unroll
     for (int j = 0; j < NRED; j++) acc[j] = 0.0;
 
-    int k = k0, r = r0, c = c0;
-    for (int chunk = wave; chunk < A.n_chunks; chunk += NW) {
-      const double pz = plane_load<TD>(rD0, k);                           // past the plane: 0
-      if (k < n && min_d < pz && pz < max_d) {                            // :280
-        const double px = ((double)c - ox) * pz * ifx;                    // :282
-        const double py = ((double)r - oy) * pz * ify;                    // :283
-        const double X = ((t15 * px + r01 * py) + r02 * pz) + cx;         // :291
-        const double Y = ((t14 * px + r11 * py) + r12 * pz) + cyy;
-        const double Zr = py * t1 + pz * t2 - px * t3;
-        const double t25 = fast_rcp(cz + Zr);                             // :294 and :313 are the same quantity
-        const double tc = (X * fx) * t25 + ox;                            // :295
-        const double tr = (Y * fy) * t25 + oy;                            // :296
-        // In bounds iff the NEAREST pixel is inside -- the same region as the reference's round() test
-        // (:297-303), so a zero-motion start never sits on the boundary; in the outer half-pixel band the
-        // taps are clamped to the edge row / column (NaN fails the comparisons).
-        if (tc > -0.5 && tc < wlim && tr > -0.5 && tr < hlim) {
-          const double fc = floor(tc), fr = floor(tr);
-          const double ax = tc - fc, ay = tr - fr;
-          const int ic = (int)fc, ir = (int)fr;
-          const int c0i = max(ic, 0), c1i = min(ic + 1, W - 1);
-          const int r0w = __mul24(max(ir, 0), W), r1w = __mul24(min(ir + 1, H - 1), W);
-          auto sample = [&](__amdgpu_buffer_rsrc_t rs) {
-            const double p00 = plane_load<TI>(rs, r0w + c0i), p01 = plane_load<TI>(rs, r0w + c1i);
-            const double p10 = plane_load<TI>(rs, r1w + c0i), p11 = plane_load<TI>(rs, r1w + c1i);
-            return (1.0 - ay) * ((1.0 - ax) * p00 + ax * p01) + ay * ((1.0 - ax) * p10 + ax * p11);
-          };
-          const double res = sample(rI1) - plane_load<TI>(rI0, k);
-          const double gxi = sample(rGX), gyi = sample(rGY);
+    // Two-stage software pipeline over the wave's chunks.  Without it the kernel was latency-bound (three quarters of
+    // every wave's cycles parked on s_waitcnt, 2.8 TB/s at the HBM side): a chunk's twelve taps can only be requested
+    // once its warp is known, and were consumed right behind the request.  Now stage `warp` of chunk i+1 (depth and
+    // source intensity requested a chunk earlier; the twelve taps go out at its end) runs BEFORE stage `consume` of
+    // chunk i (interpolation, Jacobian row, accumulation), so every tap has a whole chunk of arithmetic to arrive in.
+    // Two register sets alternate (no copies); the arithmetic of a pixel is unchanged.
+    struct Warped {
+      double px, py, pz, Zr, t25, ax, ay, i0;
+      double tap[12];                       // I1, GX, GY x (p00, p01, p10, p11)
+      unsigned long long m;                 // lanes that are valid and land in bounds
+    };
+    int k = k0;
+    double cd = cd0, rd = rd0;
+    double pz_next = plane_load<TD>(rD0, k);                              // past the plane: 0
+    double i0_next = plane_load<TI>(rI0, k);
+    auto warp = [&](Warped &w) {
+      const double pz = pz_next;
+      w.i0 = i0_next;
+      pz_next = plane_load<TD>(rD0, k + NW * WAVE);
+      i0_next = plane_load<TI>(rI0, k + NW * WAVE);
+      const double px = (cd - ox) * pz * ifx;                             // :282
+      const double py = (rd - oy) * pz * ify;                             // :283
+      const double X = ((t15 * px + r01 * py) + r02 * pz) + cx;           // :291
+      const double Y = ((t14 * px + r11 * py) + r12 * pz) + cyy;
+      const double Zr = py * t1 + pz * t2 - px * t3;
+      const double t25 = fast_rcp(cz + Zr);                               // :294 and :313 are the same quantity
+      const double tc = (X * fx) * t25 + ox;                              // :295
+      const double tr = (Y * fy) * t25 + oy;                              // :296
+      // depth gate (:280), and in bounds iff the NEAREST pixel is inside -- the same region as the reference's
+      // round() test (:297-303), so a zero-motion start never sits on the boundary; in the outer half-pixel band the
+      // taps are clamped to the edge row / column (NaN fails the comparisons).  One ballot per comparison, ANDed on
+      // the scalar unit.
+      w.m = __builtin_amdgcn_ballot_w64(k < n) & __builtin_amdgcn_ballot_w64(min_d < pz) &
+            __builtin_amdgcn_ballot_w64(pz < max_d) & __builtin_amdgcn_ballot_w64(tc > -0.5) &
+            __builtin_amdgcn_ballot_w64(tc < wlim) & __builtin_amdgcn_ballot_w64(tr > -0.5) &
+            __builtin_amdgcn_ballot_w64(tr < hlim);
+      w.px = px; w.py = py; w.pz = pz; w.Zr = Zr; w.t25 = t25;
+      if (__builtin_amdgcn_inverse_ballot_w64(w.m)) {
+        const double fc = floor(tc), fr = floor(tr);
+        w.ax = tc - fc;
+        w.ay = tr - fr;
+        const int ic = (int)fc, ir = (int)fr;
+        const int c0i = max(ic, 0), c1i = min(ic + 1, W - 1);
+        const int r0w = __mul24(max(ir, 0), W), r1w = __mul24(min(ir + 1, H - 1), W);
+        const int o00 = r0w + c0i, o01 = r0w + c1i, o10 = r1w + c0i, o11 = r1w + c1i;
+        w.tap[0] = plane_load<TI>(rI1, o00); w.tap[1] = plane_load<TI>(rI1, o01);
+        w.tap[2] = plane_load<TI>(rI1, o10); w.tap[3] = plane_load<TI>(rI1, o11);
+        w.tap[4] = plane_load<TI>(rGX, o00); w.tap[5] = plane_load<TI>(rGX, o01);
+        w.tap[6] = plane_load<TI>(rGX, o10); w.tap[7] = plane_load<TI>(rGX, o11);
+        w.tap[8] = plane_load<TI>(rGY, o00); w.tap[9] = plane_load<TI>(rGY, o01);
+        w.tap[10] = plane_load<TI>(rGY, o10); w.tap[11] = plane_load<TI>(rGY, o11);
+      }
+      k += NW * WAVE;
+      rowcol_advance(cd, rd, rc_step);
+    };
+    auto consume = [&](const Warped &w) {
+      if (__builtin_amdgcn_inverse_ballot_w64(w.m)) {
+        const double px = w.px, py = w.py, pz = w.pz, Zr = w.Zr, t25 = w.t25, ax = w.ax, ay = w.ay;
+        auto sample = [&](int b) {
+          const double p00 = w.tap[b], p01 = w.tap[b + 1], p10 = w.tap[b + 2], p11 = w.tap[b + 3];
+          return (1.0 - ay) * ((1.0 - ax) * p00 + ax * p01) + ay * ((1.0 - ax) * p10 + ax * p11);
+        };
+        const double res = sample(0) - w.i0;
+        const double gxi = sample(4), gyi = sample(8);
 
-          const double base = pz * t4 + py * t5 + px * t15;               // (pz*temp4+py*temp5+px*temp15) = X - x
-          const double Au = CORRECTED ? base + cx : base + px * cx;       // reference: px*(temp15 + x)  (:253)
-          const double Bv = py * t6 + pz * t9 + px * t14 + cyy;
-          const double Cm = -py * t16 - pz * t17 - px * t24;
-          const double Dm = py * t2 - pz * t1;
-          double J[6];
-          J[0] = (gxi * fx) * t25;
-          J[1] = (gyi * fy) * t25;
-          J[2] = -(J[0] * Au + J[1] * Bv) * t25;
-          J[3] = J[0] * (cyy - Bv) + J[1] * base;
-          J[4] = (J[0] * cosy + J[1] * siny) * Zr + Cm * J[2];
-          J[5] = J[0] * (py * t4 + pz * t21) + J[1] * (pz * t7 + py * t9) + Dm * J[2];
-          double wgt = 1.0;
-          if (huber_on) {
-            const double ar = fabs(res);
-            wgt = ar <= huber_delta ? 1.0 : huber_delta / ar;
-          }
-          int q = 0;
+        const double base = pz * t4 + py * t5 + px * t15;                 // (pz*temp4+py*temp5+px*temp15) = X - x
+        const double Au = CORRECTED ? base + cx : base + px * cx;         // reference: px*(temp15 + x)  (:253)
+        const double Bv = py * t6 + pz * t9 + px * t14 + cyy;
+        const double Cm = -py * t16 - pz * t17 - px * t24;
+        const double Dm = py * t2 - pz * t1;
+        double J[6];
+        J[0] = (gxi * fx) * t25;
+        J[1] = (gyi * fy) * t25;
+        J[2] = -(J[0] * Au + J[1] * Bv) * t25;
+        J[3] = J[0] * (cyy - Bv) + J[1] * base;
+        J[4] = (J[0] * cosy + J[1] * siny) * Zr + Cm * J[2];
+        J[5] = J[0] * (py * t4 + pz * t21) + J[1] * (pz * t7 + py * t9) + Dm * J[2];
+        double wgt = 1.0;
+        if (huber_on) {
+          const double ar = fabs(res);
+          wgt = ar <= huber_delta ? 1.0 : huber_delta / ar;
+        }
+        int q = 0;
 #pragma unroll
-          for (int a = 0; a < 6; a++) {
-            const double jw = J[a] * wgt;
+        for (int a = 0; a < 6; a++) {
+          const double jw = J[a] * wgt;
 #pragma unroll
-            for (int b = a; b < 6; b++) {
-              acc[q] = fma(jw, J[b], acc[q]);
-              q++;
-            }
-            acc[21 + a] = fma(jw, res, acc[21 + a]);
+          for (int b = a; b < 6; b++) {
+            acc[q] = fma(jw, J[b], acc[q]);
+            q++;
           }
+          acc[21 + a] = fma(jw, res, acc[21 + a]);
         }
       }
-      k += NW * WAVE; c += step_c; r += step_r;
-      if (c >= W) { c -= W; r += 1; }
+    };
+    {
+      Warped w0, w1;
+      int chunk = wave;                                                   // wave-uniform loop control throughout
+      if (chunk < A.n_chunks) {
+        warp(w0);
+        for (;;) {
+          chunk += NW;
+          const bool more1 = chunk < A.n_chunks;
+          if (more1) warp(w1);
+          consume(w0);
+          if (!more1) break;
+          chunk += NW;
+          const bool more0 = chunk < A.n_chunks;
+          if (more0) warp(w0);
+          consume(w1);
+          if (!more0) break;
+        }
+      }
     }
     reduce_solve_update<NW>(acc, lane, wave, s_red, s_state, s_cst, s_ctl, A.lambda, A.max_iter, A.min_grad_norm,
                             iteration, last_gnorm);
@@ -766,10 +820,11 @@ hipError_t launch_storage(const GNLevelArgs &a, const GNLaunchPlan &plan, int n_
 }
 
 #ifndef PHOVO_BILINEAR_WPS
-#define PHOVO_BILINEAR_WPS 3
+#define PHOVO_BILINEAR_WPS 2
 #endif
-// 256-thread workgroups per CU = waves per SIMD.  Measured on MI355X (2048 pairs, fixed iterations, fp64 / fp16 planes):
-// 4 -> 93 k / 126 k alignments/s (128 VGPRs, 86 spilled), 3 -> 116 k / 159 k (168 VGPRs), 2 -> 97 k / 134 k (no spills).
+// 256-thread workgroups per CU = waves per SIMD.  The pipelined kernel keeps two chunks' worth of taps in registers
+// (252 VGPRs): 2 -> 164 k / 175 k alignments/s (2048 pairs, fixed iterations, fp64 / fp16 planes), 3 -> 98 k / 87 k (84
+// registers spilled into the pixel loop).  Before the pipeline: 4 -> 93 k / 126 k, 3 -> 116 k / 159 k, 2 -> 97 k / 134 k.
 constexpr int BILINEAR_WPS = PHOVO_BILINEAR_WPS;
 
 template <typename TI, typename TD>

@@ -96,8 +96,6 @@ def test_two_draws_from_the_queue(kernels):
 
 def test_no_scratch_in_innermost_loops(kernels):
     for name, body in kernels.items():
-        if "bilinear" in name:
-            continue      # the opt-in bilinear extension kernel reloads 3-4 spilled pairs per pixel
         inner = set()          # names of innermost-loop header blocks, e.g. "BB10_29"
         for i, l in enumerate(body):
             if "This Inner Loop Header" in l:
