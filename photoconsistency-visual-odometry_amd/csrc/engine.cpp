@@ -37,6 +37,8 @@ struct LevelPool {
   size_t plane_off[PLANES_PER_FRAME] = {0, 0, 0, 0};
   GNLaunchPlan plan{};
   bool plan_ok = false;
+  GNLaunchPlan plan_few{};             // geometry for a handful of pairs (LATENCY_PAIRS or fewer)
+  bool plan_few_ok = false;
 };
 
 }  // namespace phovo_hip
@@ -172,6 +174,7 @@ int ensure_pairs(phovo_engine *e, int n_pairs)
   return PHOVO_OK;
 }
 
+constexpr int LATENCY_PAIRS = 8;     // up to this many pairs per launch the level kernels use the latency geometry
 enum DepthKind { DEPTH_NONE = 0, DEPTH_F64 = 1, DEPTH_U16 = 2 };
 constexpr int STAGE_CHUNK = 32;      // frames copied and processed per batch of producer launches
 
@@ -515,6 +518,7 @@ int phovo_engine_reserve_frames(phovo_engine *e, int n_frames, int width, int he
     lv.n = lv.w * lv.h;
     lv.stored = e->build_all || e->cfg.max_num_iterations[l] > 0;
     lv.plan_ok = gn_plan_level(lv.n, &lv.plan);
+    lv.plan_few_ok = gn_plan_level(lv.n, &lv.plan_few, true);
     {   // byte layout of one frame at this level: planes I, D, GX, GY.  fp64: packed [4][n] doubles, which is
         // what the producer kernels write directly; narrow storages: every plane starts 16-byte aligned.
       const bool packed = e->ext.plane_storage == PHOVO_STORAGE_F64;
@@ -833,8 +837,11 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
       }
       PHOVO_HIP_CHECK(gn_run_level_wide(a, n_pairs, e->d_wide_ws, e->h_wide_done.data(), e->stream));
     } else {
-      PHOVO_HIP_CHECK(gn_launch_level(a, lv.plan, e->ext.plane_storage, e->cu_count, e->stream));
-      if (!lv.plan.owner_in_lds) e->owner_tagged = true;     // tagged entries stay behind (the kernel wipes per pair)
+      // a handful of pairs leaves most CUs empty: take the geometry with the shorter iteration (same owner-map placement)
+      const bool few = n_pairs <= LATENCY_PAIRS && lv.plan_few_ok && lv.plan_few.owner_in_lds == lv.plan.owner_in_lds;
+      const GNLaunchPlan &pl = few ? lv.plan_few : lv.plan;
+      PHOVO_HIP_CHECK(gn_launch_level(a, pl, e->ext.plane_storage, e->cu_count, e->stream));
+      if (!pl.owner_in_lds) e->owner_tagged = true;          // tagged entries stay behind (the kernel wipes per pair)
     }
     PHOVO_HIP_CHECK(hipEventRecord(e->ev_stop[l], e->stream));
     e->level_launched[l] = true;

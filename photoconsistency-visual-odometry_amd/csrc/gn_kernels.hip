@@ -745,7 +745,7 @@ enum Variant { V_TINY = 0, V_MID, V_WIDE, V_HUGE, V_QUAD };
 
 }  // namespace
 
-bool gn_plan_level(int n, GNLaunchPlan *plan)
+bool gn_plan_level(int n, GNLaunchPlan *plan, bool prefer_latency)
 {
   const size_t n_chunks = (size_t)(n + WAVE - 1) / WAVE;
   const size_t owner = sizeof(int) * (size_t)((n + 1) & ~1);
@@ -760,7 +760,8 @@ bool gn_plan_level(int n, GNLaunchPlan *plan)
   // 2048 pairs x 50 iterations): while one workgroup's wave 0 solves, three others keep the SIMDs busy.
   // PHOVO_GN_NO_QUAD=1 is a tuning aid for tools/ only.
   static const bool no_quad = std::getenv("PHOVO_GN_NO_QUAD") != nullptr;
-  if (!no_quad && n_chunks <= 64 * 4 && f256 + owner <= LDS_LIMIT / 4) {
+  // (one pair alone on a CU: 12.4 us per 80x60 iteration with 256 threads, 10.1 us with 512 -- prefer_latency)
+  if (!no_quad && !prefer_latency && n_chunks <= 64 * 4 && f256 + owner <= LDS_LIMIT / 4) {
     plan->variant = V_QUAD; plan->threads = 256; plan->wgs_per_cu = 4; plan->owner_in_lds = true; plan->source_in_lds = false;
     plan->lds_bytes = (int)(f256 + owner);
     return true;

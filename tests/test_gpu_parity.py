@@ -460,10 +460,12 @@ def test_every_kernel_variant_matches_oracle(size, expect):
             assert info[k] == v, (k, info)
         eng.upload_frame(0, p["gray0"], p["depth0"], roles=native.ROLE_SOURCE)
         eng.upload_frame(1, p["gray1"], None, roles=native.ROLE_TARGET)
-        s, reps = eng.align_pairs([0, 0, 0], [1, 1, 1], want_reports=True)
-    assert list(reps[0].iterations[:1]) == eits
+        s, reps = eng.align_pairs([0] * 9, [1] * 9, want_reports=True)      # 9 pairs: the throughput geometry above
+        s1, reps1 = eng.align_pairs([0], [1], want_reports=True)            # a handful: the latency geometry (512 threads
+    assert list(reps[0].iterations[:1]) == eits                             # where the throughput one has 4 x 256)
     assert se3.state_distance(s[0], es) < POSE_TOL
-    assert np.array_equal(s[0], s[1]) and np.array_equal(s[0], s[2])
+    assert all(np.array_equal(s[0], s[i]) for i in range(9))
+    assert list(reps1[0].iterations[:1]) == eits and se3.state_distance(s1[0], es) < POSE_TOL
     g_last = np.linalg.norm(etr[-1]["gradient"])
     assert abs(reps[0].gradient_norm - g_last) <= 1e-9 * max(1.0, g_last)
 
