@@ -306,12 +306,17 @@ hipError_t gn_run_level_wide(const GNLevelArgs &a, int n_pairs, void *workspace,
   int *g_ctl = reinterpret_cast<int *>(w);
   const dim3 grid((unsigned)tiles, (unsigned)n_pairs);
   hipLaunchKernelGGL(k_wide_init, dim3(n_pairs), dim3(WAVE), 0, stream, a, g_cst, g_ctl);
-  const int check_every = 8;
+  // Iterations whose pairs have all stopped still cost three (empty) launches each, and asking the device costs a host
+  // round trip: with a gradient threshold the first look comes after 3 iterations (pairs typically stop after 2-4),
+  // then every 8; without one (min_gradient_norm = 0: every pair runs max_iter iterations) nobody asks at all.
+  const bool may_stop_early = a.min_grad_norm > 0.0;
+  int next_check = 3;
   for (int it = 0; it < a.max_iter; it++) {
     hipLaunchKernelGGL(k_wide_pass1, grid, dim3(WT), 0, stream, a, g_cst, g_ctl, g_mask);
     hipLaunchKernelGGL(k_wide_pass2, grid, dim3(WT), 0, stream, a, g_cst, g_ctl, g_mask, g_part, tiles);
     hipLaunchKernelGGL(k_wide_solve, dim3(n_pairs), dim3(SOLVE_T), 0, stream, a, g_cst, g_ctl, g_part, tiles);
-    if ((it + 1) % check_every == 0 && it + 1 < a.max_iter) {
+    if (may_stop_early && it + 1 >= next_check && a.max_iter - (it + 1) >= 4) {     // a look costs about three empty iterations
+      next_check = it + 1 + 8;
       hipError_t e = hipMemcpyAsync(h_done_scratch, g_ctl, sizeof(int) * W_COUNT * (size_t)n_pairs,
                                     hipMemcpyDeviceToHost, stream);
       if (e != hipSuccess) return e;
