@@ -73,20 +73,24 @@ struct phovo_engine {
   double *d_blur_kernel = nullptr;             // [levels][max ksize]
   int blur_kernel_stride = 0;
 
+  // Per-launch pair data in ONE device allocation, laid out for the pairs of the current enqueue as
+  //   [src int32 | tgt int32 | states fp64 x6 | reports | work-queue heads]
+  // so that an enqueue is one host-to-device copy (src, tgt, initial states, from the pinned mirror h_up) and one
+  // memset (reports + heads), and a fetch is one device-to-host copy (states + reports, into the pinned h_down).
   int pair_capacity = 0;
-  int *d_src = nullptr, *d_tgt = nullptr;
+  unsigned char *d_pairs = nullptr;
+  unsigned char *h_up = nullptr, *h_down = nullptr;      // pinned
+  int *d_src = nullptr, *d_tgt = nullptr;                // views into d_pairs for the current enqueue
   double *d_states = nullptr;
   phovo_pair_report *d_reports = nullptr;
   int *d_owner = nullptr;
   size_t owner_capacity = 0;
   bool owner_tagged = false;                   // d_owner holds tagged entries of the persistent kernel, not the -1 the wide form expects
-  int *d_work_counters = nullptr;              // [PHOVO_MAX_LEVELS] pair counters of the persistent kernels' work queues
+  int *d_work_counters = nullptr;              // [PHOVO_MAX_LEVELS] work-queue heads of the level launches (view into d_pairs)
   int cu_count = 256;
   void *d_wide_ws = nullptr;                   // workspace of the wide (many-workgroups-per-pair) level form
   size_t wide_ws_capacity = 0;
   std::vector<int> h_wide_done;
-  std::vector<int> h_src, h_tgt;               // host copies of the last pair list / initial states (see enqueue)
-  std::vector<double> h_init;
   int wide_policy = 0;                         // 0 auto, 1 always (where possible), -1 never
   int last_pairs = 0;
 };
@@ -114,10 +118,10 @@ void free_pool(phovo_engine *e)
 
 void free_pairs(phovo_engine *e)
 {
-  if (e->d_src) (void)hipFree(e->d_src);
-  if (e->d_tgt) (void)hipFree(e->d_tgt);
-  if (e->d_states) (void)hipFree(e->d_states);
-  if (e->d_reports) (void)hipFree(e->d_reports);
+  if (e->d_pairs) (void)hipFree(e->d_pairs);
+  if (e->h_up) (void)hipHostFree(e->h_up);
+  if (e->h_down) (void)hipHostFree(e->h_down);
+  e->d_pairs = nullptr; e->h_up = e->h_down = nullptr; e->d_work_counters = nullptr;
   if (e->d_owner) (void)hipFree(e->d_owner);
   if (e->d_wide_ws) (void)hipFree(e->d_wide_ws);
   e->d_wide_ws = nullptr; e->wide_ws_capacity = 0;
@@ -156,6 +160,23 @@ bool use_wide_level(const phovo_engine *e, int n_pairs, int n_pixels)
   return n_pairs * 8 <= 256 && n_pixels >= 16384;
 }
 
+// Byte offsets of the per-launch pair data for n pairs (see phovo_engine::d_pairs); every section starts 8-byte aligned.
+struct PairLayout {
+  size_t src, tgt, states, reports, heads, total;
+};
+PairLayout pair_layout(int n_pairs)
+{
+  const size_t n2 = ((size_t)n_pairs + 1) & ~(size_t)1;      // two int32 per 8 bytes
+  PairLayout l;
+  l.src = 0;
+  l.tgt = l.src + sizeof(int) * n2;
+  l.states = l.tgt + sizeof(int) * n2;
+  l.reports = l.states + sizeof(double) * 6 * (size_t)n_pairs;
+  l.heads = l.reports + sizeof(phovo_pair_report) * (size_t)n_pairs;
+  l.total = l.heads + sizeof(int) * PHOVO_MAX_LEVELS;
+  return l;
+}
+
 int ensure_pairs(phovo_engine *e, int n_pairs)
 {
   if (n_pairs <= e->pair_capacity) return PHOVO_OK;
@@ -166,10 +187,10 @@ int ensure_pairs(phovo_engine *e, int n_pairs)
   free_pairs(e);
   e->d_owner = keep; e->owner_capacity = keep_owner;
   e->d_wide_ws = keep_ws; e->wide_ws_capacity = keep_ws_cap;
-  PHOVO_HIP_CHECK(hipMalloc(&e->d_src, sizeof(int) * (size_t)n_pairs));
-  PHOVO_HIP_CHECK(hipMalloc(&e->d_tgt, sizeof(int) * (size_t)n_pairs));
-  PHOVO_HIP_CHECK(hipMalloc(&e->d_states, sizeof(double) * 6 * (size_t)n_pairs));
-  PHOVO_HIP_CHECK(hipMalloc(&e->d_reports, sizeof(phovo_pair_report) * (size_t)n_pairs));
+  const PairLayout cap = pair_layout(n_pairs);
+  PHOVO_HIP_CHECK(hipMalloc(&e->d_pairs, cap.total));
+  PHOVO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&e->h_up), cap.reports, hipHostMallocDefault));
+  PHOVO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&e->h_down), cap.heads - cap.states, hipHostMallocDefault));
   e->pair_capacity = n_pairs;
   return PHOVO_OK;
 }
@@ -363,7 +384,6 @@ int phovo_engine_create(int device, phovo_engine **out)
     }
   }
   if (he == hipSuccess) he = gn_prepare_kernels();
-  if (he == hipSuccess) he = hipMalloc(&e->d_work_counters, sizeof(int) * PHOVO_MAX_LEVELS);
   if (he == hipSuccess) {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) e->cu_count = cus;
@@ -383,7 +403,6 @@ int phovo_engine_destroy(phovo_engine *e)
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   free_pool(e);
   free_pairs(e);
-  if (e->d_work_counters) (void)hipFree(e->d_work_counters);
   for (int l = 0; l < PHOVO_MAX_LEVELS; l++) {
     if (e->ev_start[l]) (void)hipEventDestroy(e->ev_start[l]);
     if (e->ev_stop[l]) (void)hipEventDestroy(e->ev_stop[l]);
@@ -791,19 +810,21 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
   // engine-owned copies alive until the next enqueue (the previous ones are no longer in flight: the stream
   // is in order and their copies precede everything enqueued since).
   PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
-  e->h_src.assign(source_frames, source_frames + n_pairs);
-  e->h_tgt.assign(target_frames, target_frames + n_pairs);
-  PHOVO_HIP_CHECK(hipMemcpyAsync(e->d_src, e->h_src.data(), sizeof(int) * (size_t)n_pairs, hipMemcpyHostToDevice, e->stream));
-  PHOVO_HIP_CHECK(hipMemcpyAsync(e->d_tgt, e->h_tgt.data(), sizeof(int) * (size_t)n_pairs, hipMemcpyHostToDevice, e->stream));
-  if (init_states) {                                                                 // SetInitialStateVector  :494
-    e->h_init.assign(init_states, init_states + 6 * (size_t)n_pairs);
-    PHOVO_HIP_CHECK(hipMemcpyAsync(e->d_states, e->h_init.data(), sizeof(double) * 6 * (size_t)n_pairs, hipMemcpyHostToDevice, e->stream));
-  } else
-    PHOVO_HIP_CHECK(hipMemsetAsync(e->d_states, 0, sizeof(double) * 6 * (size_t)n_pairs, e->stream));
-  PHOVO_HIP_CHECK(hipMemsetAsync(e->d_reports, 0, sizeof(phovo_pair_report) * (size_t)n_pairs, e->stream));
+  const PairLayout pl = pair_layout(n_pairs);
+  e->d_src = reinterpret_cast<int *>(e->d_pairs + pl.src);
+  e->d_tgt = reinterpret_cast<int *>(e->d_pairs + pl.tgt);
+  e->d_states = reinterpret_cast<double *>(e->d_pairs + pl.states);
+  e->d_reports = reinterpret_cast<phovo_pair_report *>(e->d_pairs + pl.reports);
+  e->d_work_counters = reinterpret_cast<int *>(e->d_pairs + pl.heads);
+  std::memset(e->h_up, 0, pl.reports);
+  std::memcpy(e->h_up + pl.src, source_frames, sizeof(int) * (size_t)n_pairs);
+  std::memcpy(e->h_up + pl.tgt, target_frames, sizeof(int) * (size_t)n_pairs);
+  if (init_states)                                                                   // SetInitialStateVector  :494
+    std::memcpy(e->h_up + pl.states, init_states, sizeof(double) * 6 * (size_t)n_pairs);
+  // one copy in (pair list + initial states, zeros without them), one memset (reports + the work-queue heads of all levels)
+  PHOVO_HIP_CHECK(hipMemcpyAsync(e->d_pairs, e->h_up, pl.reports, hipMemcpyHostToDevice, e->stream));
+  PHOVO_HIP_CHECK(hipMemsetAsync(e->d_pairs + pl.reports, 0, pl.total - pl.reports, e->stream));
 
-  // the work-queue heads of all levels (one int each), cleared by one node ahead of the level launches
-  PHOVO_HIP_CHECK(hipMemsetAsync(e->d_work_counters, 0, sizeof(int) * PHOVO_MAX_LEVELS, e->stream));
   for (int l = e->cfg.num_levels - 1; l >= 0; l--) {                                 // coarse to fine  :502-503
     if (e->cfg.max_num_iterations[l] <= 0) continue;                                 // :526 (nothing observable happens)
     const LevelPool &lv = e->levels[l];
@@ -864,11 +885,14 @@ int phovo_engine_fetch_results(phovo_engine *e, int n_pairs, double *out_states,
   if (n_pairs != e->last_pairs) return fail(PHOVO_E_INVALID_ARGUMENT, "fetch_results: n_pairs differs from the last enqueue");
   if (n_pairs == 0) return PHOVO_OK;
   PHOVO_HIP_CHECK(hipSetDevice(e->device));
+  const PairLayout pl = pair_layout(n_pairs);
+  // one copy out: states (and reports right behind them, when asked for) into pinned memory
+  const size_t bytes = (reports ? pl.heads : pl.reports) - pl.states;
+  PHOVO_HIP_CHECK(hipMemcpyAsync(e->h_down, e->d_pairs + pl.states, bytes, hipMemcpyDeviceToHost, e->stream));
   PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
-  if (out_states)
-    PHOVO_HIP_CHECK(hipMemcpy(out_states, e->d_states, sizeof(double) * 6 * (size_t)n_pairs, hipMemcpyDeviceToHost));
+  if (out_states) std::memcpy(out_states, e->h_down, sizeof(double) * 6 * (size_t)n_pairs);
   if (reports) {
-    PHOVO_HIP_CHECK(hipMemcpy(reports, e->d_reports, sizeof(phovo_pair_report) * (size_t)n_pairs, hipMemcpyDeviceToHost));
+    std::memcpy(reports, e->h_down + (pl.reports - pl.states), sizeof(phovo_pair_report) * (size_t)n_pairs);
     // Levels with max_num_iterations == 0 still run the loop body once in the reference (:510,547-549).
     for (int i = 0; i < n_pairs; i++)
       for (int l = 0; l < e->cfg.num_levels; l++)
