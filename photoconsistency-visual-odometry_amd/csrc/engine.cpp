@@ -861,6 +861,7 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
       // a handful of pairs leaves most CUs empty: take the geometry with the shorter iteration (same owner-map placement)
       const bool few = n_pairs <= LATENCY_PAIRS && lv.plan_few_ok && lv.plan_few.owner_in_lds == lv.plan.owner_in_lds;
       const GNLaunchPlan &pl = few ? lv.plan_few : lv.plan;
+      a.n_lds = pl.owner_in_lds ? 0 : pl.owner_lds_entries;
       PHOVO_HIP_CHECK(gn_launch_level(a, pl, e->ext.plane_storage, e->cu_count, e->stream));
       if (!pl.owner_in_lds) e->owner_tagged = true;          // tagged entries stay behind (the kernel wipes per pair)
     }

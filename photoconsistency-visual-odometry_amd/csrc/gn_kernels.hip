@@ -57,8 +57,9 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
   int *s_ctl = reinterpret_cast<int *>(s_red + NW * NRED);             // [CTL_COUNT]
   unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(s_ctl + CTL_COUNT);  // [n_chunks] (!MASK_REG)
   unsigned char *p = reinterpret_cast<unsigned char *>(s_mask + (MASK_REG ? 0 : A.n_chunks));
-  int *s_owner = reinterpret_cast<int *>(p);                           // [n]      (OWNER_LDS)
+  int *s_owner = reinterpret_cast<int *>(p);                           // [n] (OWNER_LDS) or [n_lds] (owner map in HBM)
   if (OWNER_LDS) p += sizeof(int) * ((A.n + 1) & ~1);
+  const int n_lds = OWNER_LDS ? 0 : A.n_lds;      // owner map in HBM: targets below n_lds are resolved in LDS all the same
   double *s_i0 = reinterpret_cast<double *>(p);                        // [n]      (SRC_LDS)
 
   const int tid = threadIdx.x;
@@ -101,7 +102,8 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
     // Owner map in HBM: entries carry the iteration they were written in (OWNER_TAG_SHIFT), so nothing has to be
     // reset between iterations; it is wiped once per pair here (the barrier below waits for the stores, and the
     // map is touched by this workgroup only).
-    for (int k = tid; k < n; k += T) g_owner[k] = -1;
+    for (int k = tid; k < n_lds; k += T) s_owner[k] = -1;
+    for (int k = n_lds + tid; k < n; k += T) g_owner[k] = -1;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   }
   if (SRC_LDS) {
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
     if constexpr (!OWNER_LDS) {
       const int tg = iteration % OWNER_TAG_PERIOD + 1;
       if (iteration > 0 && tg == 1) {                                     // uniform: every wave takes it
-        for (int kk = tid; kk < n; kk += T) g_owner[kk] = -1;
+        for (int kk = n_lds + tid; kk < n; kk += T) g_owner[kk] = -1;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
       }
@@ -279,8 +281,12 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
           }
 #pragma unroll
           for (int g = 0; g < G; g++) {
-            if (g < count && __builtin_amdgcn_inverse_ballot_w64(pend_m[g]))
-              atomicMax(&g_owner[pend_t[g]], pend_v[g]);                  // last raster writer of THIS iteration wins  :358
+            if (g < count && __builtin_amdgcn_inverse_ballot_w64(pend_m[g])) {
+              // last raster writer of THIS iteration wins (:358); the leading n_lds targets are resolved in LDS (plain
+              // source index, reset by pass 2), the others in HBM (tagged)
+              if (pend_t[g] < n_lds) atomicMax(&s_owner[pend_t[g]], pend_v[g] & OWNER_INDEX_MASK);
+              else atomicMax(&g_owner[pend_t[g]], pend_v[g]);
+            }
           }
 #pragma unroll
           for (int g = 0; g < G; g++) pzg[g] = pzn[g];
@@ -317,8 +323,8 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
       // of earlier iterations fail the tag comparison, so nothing is written back (a store per chunk would hold up
       // every later load of the wave: the memory counter retires in order).
       int o_raw = -1;
-      auto owner_request = [&](int kk) {
-        o_raw = kk < n ? __hip_atomic_load(&g_owner[kk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+      auto owner_request = [&](int kk) {       // (entries below n_lds are in LDS: nothing to request)
+        o_raw = (kk >= n_lds && kk < n) ? __hip_atomic_load(&g_owner[kk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
       };
       if (!OWNER_LDS) owner_request(k);
       auto fetch = [&](int kk) {
@@ -329,7 +335,12 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
             s_owner[kk] = -1;                       // ready for the next iteration
           }
         } else {
-          o_n = (o_raw & ~OWNER_INDEX_MASK) == owner_tag ? (o_raw & OWNER_INDEX_MASK) : -1;
+          if (kk < n_lds) {                         // n_lds is a multiple of 64: the whole chunk is on one side
+            o_n = s_owner[kk];
+            s_owner[kk] = -1;
+          } else {
+            o_n = (o_raw & ~OWNER_INDEX_MASK) == owner_tag ? (o_raw & OWNER_INDEX_MASK) : -1;
+          }
           owner_request(kk + NW * WAVE);
         }
         pz_n = plane_load<TD>(rD0, kk);
@@ -747,6 +758,7 @@ enum Variant { V_TINY = 0, V_MID, V_WIDE, V_HUGE, V_QUAD };
 
 bool gn_plan_level(int n, GNLaunchPlan *plan, bool prefer_latency)
 {
+  plan->owner_lds_entries = 0;
   const size_t n_chunks = (size_t)(n + WAVE - 1) / WAVE;
   const size_t owner = sizeof(int) * (size_t)((n + 1) & ~1);
   const size_t src = sizeof(double) * (size_t)n;
@@ -782,8 +794,13 @@ bool gn_plan_level(int n, GNLaunchPlan *plan, bool prefer_latency)
   const size_t mask = sizeof(unsigned long long) * n_chunks;
   if (f1024 + mask > LDS_LIMIT) return false;
   if (n > OWNER_INDEX_MASK) return false;          // the tagged entries of the HBM owner map hold 21-bit indices
+  // whatever LDS the ballot masks leave free holds the leading part of the owner map (whole 64-pixel chunks)
+  static const bool no_split = std::getenv("PHOVO_GN_NO_OWNER_SPLIT") != nullptr;      // tuning aid for tools/
+  const size_t spare = LDS_LIMIT - f1024 - mask;
+  plan->owner_lds_entries = no_split ? 0 : (int)((spare / sizeof(int)) / WAVE * WAVE);
+  if (plan->owner_lds_entries > n) plan->owner_lds_entries = (n / WAVE) * WAVE;
   plan->variant = V_HUGE; plan->threads = 1024; plan->wgs_per_cu = 1; plan->owner_in_lds = false; plan->source_in_lds = false;
-  plan->lds_bytes = (int)(f1024 + mask);
+  plan->lds_bytes = (int)(f1024 + mask + sizeof(int) * (size_t)plan->owner_lds_entries);
   return true;
 }
 

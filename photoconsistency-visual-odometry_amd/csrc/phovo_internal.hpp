@@ -35,6 +35,7 @@ struct GNLevelArgs {
   int *g_owner;             // [pairs][n] owner map in global memory (only when it does not fit LDS)
   int n_pairs;              // pairs of this launch
   int *work_counter;        // zeroed before the launch: workgroups draw pair indices from it (work queue)
+  int n_lds;                // owner map in HBM only: its first n_lds entries (a multiple of 64) live in LDS instead
 };
 
 struct GNLaunchPlan {
@@ -44,6 +45,7 @@ struct GNLaunchPlan {
   int lds_bytes;            // dynamic LDS
   bool owner_in_lds;
   bool source_in_lds;
+  int owner_lds_entries;    // owner map in HBM: how many of its leading entries the leftover LDS holds (GNLevelArgs::n_lds)
 };
 
 // Chooses the launch geometry for a level of n pixels.  Returns false if the level cannot be
