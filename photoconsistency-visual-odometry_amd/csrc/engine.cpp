@@ -173,7 +173,7 @@ PairLayout pair_layout(int n_pairs)
   l.states = l.tgt + sizeof(int) * n2;
   l.reports = l.states + sizeof(double) * 6 * (size_t)n_pairs;
   l.heads = l.reports + sizeof(phovo_pair_report) * (size_t)n_pairs;
-  l.total = l.heads + sizeof(int) * PHOVO_MAX_LEVELS;
+  l.total = l.heads + sizeof(int) * PHOVO_MAX_LEVELS * QUEUES_PER_LEVEL;
   return l;
 }
 
@@ -847,7 +847,11 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
     a.states = e->d_states; a.reports = e->d_reports;
     a.g_owner = e->d_owner;
     a.n_pairs = n_pairs;
-    a.work_counter = e->d_work_counters + l;
+    a.work_counter = e->d_work_counters + l * QUEUES_PER_LEVEL;
+    // one queue per XCD once there are enough pairs to keep every XCD's share of the grid busy; PHOVO_QUEUE_SINGLE=1
+    // is a tuning aid for tools/ (A/B of the placement)
+    static const bool single_queue = std::getenv("PHOVO_QUEUE_SINGLE") != nullptr;
+    a.n_queues = (!single_queue && n_pairs >= 8 * 64) ? QUEUES_PER_LEVEL : 1;
     PHOVO_HIP_CHECK(hipEventRecord(e->ev_start[l], e->stream));
     if (e->ext.sampling == PHOVO_SAMPLING_BILINEAR)
       PHOVO_HIP_CHECK(gn_launch_level_bilinear(a, e->ext.plane_storage, e->ext.jacobian_corrected != 0, e->cu_count, e->stream));

@@ -221,6 +221,28 @@ __device__ __forceinline__ double round_half_up_from(double v)
   return t + __hiloint2double(f >= 0.5 ? 0x3ff00000 : 0, 0);          // + 1.0 or + 0.0: one select on the high word
 }
 
+// Next pair of the work queue for the calling workgroup (one thread calls this), or n_pairs when everything is taken.
+// With 8 queues, queue q serves the q-th contiguous eighth of the pair list and a workgroup starts with the queue of
+// its XCD -- the hardware deals workgroups to the 8 XCDs round-robin, so blockIdx & 7 -- which keeps consecutive pairs
+// of a sequence (they share a frame: the target of one is the source of the next) on one XCD's L2 at the same time;
+// an empty queue sends the caller on to the next one.
+__device__ __forceinline__ int draw_pair(int *heads, int n_queues, int n_pairs)
+{
+  if (n_queues <= 1) return atomicAdd(heads, 1);
+  const int per = (n_pairs + n_queues - 1) / n_queues;
+  int q = (int)(blockIdx.x & (unsigned)(n_queues - 1));
+  for (int tries = 0; tries < n_queues; tries++) {
+    const int first = q * per;
+    const int size = first >= n_pairs ? 0 : (first + per > n_pairs ? n_pairs - first : per);
+    if (size > 0) {
+      const int t = atomicAdd(heads + q, 1);
+      if (t < size) return first + t;
+    }
+    q = (q + 1) & (n_queues - 1);
+  }
+  return n_pairs;
+}
+
 // v_writelane_b32: lane `lane` (wave-uniform) of `old` becomes `value` (wave-uniform); the other lanes keep theirs.
 // clang has builtins for readlane / readfirstlane but none for writelane, so the LLVM intrinsic is declared by name
 // (the device libraries do the same for intrinsics without a builtin).  Inline assembly is not an option: the lane

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
   // the iteration loop and the barrier at the head of the work loop is one if-block (two adjacent `if (tid == 0)`
   // blocks, one either side of the back edge, were threaded together by the compiler into a loop that reached that
   // barrier with thread 0 parked: a hang).
-  if (tid == 0) s_ctl[CTL_PAIR] = atomicAdd(A.work_counter, 1);
+  if (tid == 0) s_ctl[CTL_PAIR] = draw_pair(A.work_counter, A.n_queues, A.n_pairs);
   for (;;) {
   // The ticket thread 0 has just stored must have LEFT its LDS queue before any wave is released: the compiler omits
   // the wait in front of this one barrier (it relies on LDS operations being ordered across waves), and on the GPU
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
       A.reports[pair].iterations[15] = (int)blockIdx.x;
 #endif
     }
-    s_ctl[CTL_PAIR] = atomicAdd(A.work_counter, 1);
+    s_ctl[CTL_PAIR] = draw_pair(A.work_counter, A.n_queues, A.n_pairs);
   }
   }   // next pair
 }
@@ -540,7 +540,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel_bilinear(const GNLevel
   const int lane = tid & (WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
   const int n = A.n, W = A.w, H = A.h;
-  if (tid == 0) s_ctl[CTL_PAIR] = atomicAdd(A.work_counter, 1);
+  if (tid == 0) s_ctl[CTL_PAIR] = draw_pair(A.work_counter, A.n_queues, A.n_pairs);
   for (;;) {                                // work queue, as in gn_level_kernel
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // see gn_level_kernel
   __syncthreads();
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel_bilinear(const GNLevel
       A.reports[pair].gradient_norm = last_gnorm;
       A.reports[pair].flags |= (uint32_t)s_ctl[CTL_FLAGS];
     }
-    s_ctl[CTL_PAIR] = atomicAdd(A.work_counter, 1);
+    s_ctl[CTL_PAIR] = draw_pair(A.work_counter, A.n_queues, A.n_pairs);
   }
   }   // next pair
 }

@@ -34,9 +34,12 @@ struct GNLevelArgs {
   phovo_pair_report *reports;   // [pairs]
   int *g_owner;             // [pairs][n] owner map in global memory (only when it does not fit LDS)
   int n_pairs;              // pairs of this launch
-  int *work_counter;        // zeroed before the launch: workgroups draw pair indices from it (work queue)
+  int *work_counter;        // [QUEUES_PER_LEVEL] heads, zeroed before the launch: workgroups draw pair indices from them
+  int n_queues;             // 1: one queue for the whole grid; 8: one per XCD over a contiguous eighth of the pairs (+ stealing)
   int n_lds;                // owner map in HBM only: its first n_lds entries (a multiple of 64) live in LDS instead
 };
+
+constexpr int QUEUES_PER_LEVEL = 8;      // one per XCD
 
 struct GNLaunchPlan {
   int variant;              // which instantiation of the level kernel (gn_kernels.hip)

@@ -91,7 +91,9 @@ def test_every_barrier_waits_for_lds_first():
 def test_two_draws_from_the_queue(kernels):
     for name, body in kernels.items():
         n = sum("global_atomic_add" in l for l in body)
-        assert n == 2, f"{name}: {n} atomic adds (one draw before the loop, one in the write-back block)"
+        # two draw sites (before the loop, in the write-back block), each with the single-queue add and the
+        # per-XCD-queue add of draw_pair
+        assert n == 4, f"{name}: {n} atomic adds, expected 2 draw sites x 2 queue forms"
 
 
 def test_no_scratch_in_innermost_loops(kernels):
