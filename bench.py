@@ -27,8 +27,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import phovo_amd  # noqa: E402,F401
-from phovo_amd import distributed, native, odometry, synthetic  # noqa: E402
+# The package (and with it libphovo_hip.so / the HIP runtime) is imported in main(), AFTER the self-launch decision:
+# the parent of a `python bench.py --gpus N` run must never touch the GPU (launch_ranks below).
+distributed = native = odometry = se3 = synthetic = None
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 # headline workload (BASELINE.json configs[1] / configs[3]); --workload cfg5 switches to configs[4]'s shape
@@ -106,8 +107,49 @@ def run_steps(eng, src, tgt, steps, use_dist, device, n_global):
     return time.perf_counter() - t0, per_level
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves.
+
+    This process has not imported torch, the package or anything else that could initialise the GPU; it starts
+    `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a CHILD (never an exec: a
+    process that has touched the GPU must not be replaced, and this one stays around to relay the result), passes the
+    children's stderr through, prints rank 0's single JSON line on its own stdout and exits with the children's
+    status.  Under a launcher (RANK set, the driver's documented form) this function is not reached."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:           # a free rendezvous port
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")                      # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"bench.py: starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:                       # rank 0 prints exactly one JSON line; anything else goes to stderr
+        t = out.strip()
+        if t.startswith("{") and '"metric"' in t:
+            line = t
+        elif t:
+            print(t, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        print("bench.py: the ranks exited cleanly but rank 0 printed no result line", file=sys.stderr)
+        rc = 1
+    sys.exit(rc)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        launch_ranks(args)                        # does not return
+    global distributed, native, odometry, se3, synthetic
+    import phovo_amd  # noqa: F401
+    from phovo_amd import distributed, native, odometry, se3, synthetic
     wl = WORKLOADS[args.workload]
     YML = os.path.join(ROOT, "config_files", wl["yml"])
     W, H = wl["size"]
@@ -141,6 +183,7 @@ def main():
             local_rank = local_rank % max(n_dev, 1)
             device = torch.device("cpu")
             dist.init_process_group(backend)
+        print(f"bench.py: rank {rank}/{world} joined the {backend} group", file=sys.stderr, flush=True)
 
     use_dist = dist is not None
     if native.lib().phovo_device_count() < 1:
@@ -315,19 +358,32 @@ def main():
                           "reference's FrameAlignment app times it): latency-bound, one workgroup per level")
 
     # ---- CPU baseline: the oracle, one thread, bounded sample of the same workload ------------
-    cpu = None
+    cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle
         ocfg = oracle.make_config(num_levels=nl, max_iter=max_iter, min_grad=[0.0] * nl)
         done, t_cpu, t = 0, 0.0, 0
+        # The oracle's poses of this leg are kept and compared -- outside every timed region -- with the poses the
+        # timed GPU steps left in `states` (slot t of replica 0 is the pair (frame t, frame t+1)): the checker
+        # checking the thing measured, on the full 50 + 20 iterations no clipped test reaches.
+        check_parity = plain_mode and args.storage == "f64"
+        worst, its_equal, checked = 0.0, True, set()
         while t_cpu < args.cpu_seconds:
             i0p, d0p = oracle.build_source_pyramids(seq["gray"][t], seq["depth"][t], ocfg)
             i1p, gxp, gyp = oracle.build_target_pyramids(seq["gray"][t + 1], ocfg)
             c0 = time.perf_counter()
-            oracle.optimize(ocfg, seq["K"], i0p, d0p, i1p, gxp, gyp)      # Optimize() only, as the reference times it
+            es, eits = oracle.optimize(ocfg, seq["K"], i0p, d0p, i1p, gxp, gyp)   # Optimize() only, as the reference times it
             t_cpu += time.perf_counter() - c0
             done += 1
+            if check_parity and t not in checked and t < n_local:
+                checked.add(t)
+                worst = max(worst, float(se3.state_distance(states[t], es)))
+                its_equal = its_equal and [int(v) for v in iters[t]] == [int(v) for v in eits]
             t = (t + 1) % distinct
+        if check_parity:
+            parity = dict(checked=len(checked), max_pose_distance=worst, iterations_equal=bool(its_equal),
+                          bar=1e-5, note="poses of the timed steps vs the CPU oracle on the same pairs, "
+                                         "||log(T_gpu^-1 T_cpu)||; compared outside the timed region")
         cpu = dict(value=done / t_cpu, unit="alignments/s", cores=1, kind="port",
                    sample=f"{done} alignments over the same synthetic {W}x{H} pairs, fixed-iteration mode, Optimize() only "
                           f"({t_cpu:.1f} s, gcc -O3 -mtune=native, single thread as the reference builds)",
@@ -372,7 +428,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64",
+            # arithmetic is fp64 in every mode; a narrow plane storage (an extension, never the default) is named too
+            "dtype": "f64" if args.storage == "f64" else f"f64 arithmetic on {args.storage} planes",
             "data": "synthetic",
             "config": {
                 "workload": f"{wl['yml']} on synthetic {W}x{H} RGB-D, fixed-iteration mode (min_gradient_norm=0: "
@@ -386,6 +443,7 @@ def main():
             },
             "iterations_per_pair": [float(x) for x in iters.mean(axis=0)],
             "nonfinite_pairs": nonfinite,
+            "parity": parity,
             "algorithmic_MB_per_alignment": algorithmic_bytes(
                 level_sizes, [m if max_iter[l] > 0 else 0.0 for l, m in enumerate(iters.mean(axis=0))]) / 1e6
             * plane_bytes / 40.0,

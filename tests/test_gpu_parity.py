@@ -179,6 +179,46 @@ def test_batched_alignment_matches_oracle_on_identical_pyramids(vga_pairs, yml, 
         assert abs(reps[i].gradient_norm - g_last) <= 1e-9 * max(1.0, g_last)
 
 
+@pytest.mark.parametrize("yml", ["config_4_level_optimization_analytic.yml",
+                                 "config_5_level_optimization_analytic.yml"])
+def test_full_depth_fixed_iteration_mode_matches_oracle(yml):
+    """The mode bench.py times, unclipped: min_gradient_norm = 0 and the yml's own max_num_iterations ([0,0,20,50] /
+    [0,0,5,20,50]) on 640x480, i.e. up to 70 Gauss-Newton iterations per pair, most of them past convergence, on an
+    objective whose round() makes it discontinuous -- exactly where a flipped rounding decision would show
+    (...Analytic.h:297-298,500-563).  Ten seeded pairs (holes, small and large motions), each replicated so that the
+    launch takes the throughput geometry; same bar as everywhere: identical iteration counts, pose within 1e-9."""
+    ncfg = native.read_config_file(os.path.join(CFG_DIR, yml))
+    nl = ncfg.num_levels
+    max_iter = list(ncfg.max_num_iterations[:nl])
+    ncfg, ocfg = _cfgs(nl, max_iter, [0.0] * nl)
+    probs = [synthetic.make_pair(60 + i, 640, 480, holes=(0.0, 0.02, 0.05)[i % 3],
+                                 trans=(0.004, 0.015, 0.03, 0.05)[i % 4], rot=(0.002, 0.008, 0.015, 0.025)[i % 4])
+             for i in range(10)]
+    expect = [oracle.align_frames(ocfg, p["K"], p["gray0"], p["depth0"], p["gray1"]) for p in probs]
+    reps_per = 4
+    with odometry.AlignmentEngine() as eng:
+        eng.set_config(ncfg)
+        eng.set_intrinsic_matrix(probs[0]["K"])
+        eng.reserve_frames(2 * len(probs), 640, 480)
+        for i, p in enumerate(probs):
+            eng.upload_frame(2 * i, p["gray0"], p["depth0"], roles=native.ROLE_SOURCE)
+            eng.upload_frame(2 * i + 1, p["gray1"], None, roles=native.ROLE_TARGET)
+        src = [2 * i for i in range(len(probs))] * reps_per
+        tgt = [2 * i + 1 for i in range(len(probs))] * reps_per
+        states, reps = eng.align_pairs(src, tgt, want_reports=True)
+    worst = 0.0
+    for k in range(len(src)):
+        i = k % len(probs)
+        es, eits = expect[i]
+        assert list(reps[k].iterations[:nl]) == eits == [m if m > 0 else 1 for m in max_iter], (k, eits)
+        d = se3.state_distance(states[k], es)
+        worst = max(worst, d)
+        assert d < POSE_TOL, (k, d)
+        assert reps[k].flags == 0
+        assert np.array_equal(states[k], states[i])
+    print(f"full-depth fixed-iteration parity: worst pose distance {worst:.3e}")
+
+
 def test_device_pyramid_path_end_to_end_matches_oracle(vga_pairs):
     """Raw u8 + depth in, pose out: SetSourceFrame/SetTargetFrame/Optimize as the apps call them."""
     ncfg = native.read_config_file(os.path.join(CFG_DIR, "config_4_level_optimization_analytic.yml"))
