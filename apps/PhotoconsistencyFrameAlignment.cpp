@@ -77,6 +77,27 @@ int main(int argc, char **argv)
     const auto t1 = std::chrono::steady_clock::now();
     std::cout << "Time = " << std::chrono::duration<double>(t1 - t0).count() << " sec." << std::endl;
 
+    // The reference prints a progress block per level when built with ENABLE_PRINT_CONSOLE_OPTIMIZATION_PROGRESS
+    // (...Analytic.h:40,396-421; off as shipped).  Here the block is a run-time opt-in, printed after the fact from
+    // the device's report, coarse to fine as Optimize() visits the levels (:502-503).
+    if (std::getenv("PHOVO_PRINT_OPTIMIZATION_PROGRESS")) {
+      phovo_config cfg;
+      if (phovo_config_read_file(argv[1], &cfg) == PHOVO_OK) {
+        const phovo_pair_report rep = photoconsistencyOdometry.GetReport();
+        for (int level = cfg.num_levels - 1; level >= 0; level--) {
+          std::cout << "----------------------------------------" << std::endl;
+          std::cout << "Optimization level: " << level << std::endl;
+          std::cout << "Number iterations: " << rep.iterations[level] << std::endl;
+          // the report keeps the gradient norm of the LAST active level only (the reference's m_Gradients is likewise
+          // overwritten level by level)
+          int last_active = 0;
+          for (int l = 0; l < cfg.num_levels; l++) if (cfg.max_num_iterations[l] > 0) { last_active = l; break; }
+          if (level == last_active) std::cout << "gradient norm: " << rep.gradient_norm << std::endl;
+          std::cout << "----------------------------------------" << std::endl;
+        }
+      }
+    }
+
     Matrix44Type Rt = photoconsistencyOdometry.GetOptimalRigidTransformationMatrix();
     std::cout << "main::Rt eigen:" << std::endl << Rt << std::endl;
 

@@ -36,7 +36,6 @@ typedef unsigned char PixelType;
 typedef phovo::Numeric::Matrix33RowMajor<CoordinateType> Matrix33Type;
 typedef phovo::Numeric::Matrix44RowMajor<CoordinateType> Matrix44Type;
 typedef phovo::Numeric::VectorCol6<CoordinateType> Vector6Type;
-typedef phovo::Numeric::Quaternion<CoordinateType> QuaternionType;
 typedef phovo::compat::Mat_<PixelType> IntensityImageType;
 typedef phovo::compat::Mat_<CoordinateType> DepthImageType;
 
@@ -84,13 +83,14 @@ static bool loadDepth16(const std::string &path, phovo_io::Image16 &im)
   return true;
 }
 
-static void writePose(std::ofstream &f, double timestamp, const Matrix44Type &pose)
+// pose chain and trajectory line live behind the C ABI (phovo_trajectory_*): this loop, the --batch path and the
+// multi-rank sequence driver write byte-identical files
+static bool writePose(std::ofstream &f, double timestamp, const Matrix44Type &pose)
 {
-  const Matrix33Type R = pose.block<3, 3>(0, 0);
-  const QuaternionType q(R);
-  f << std::setprecision(std::numeric_limits<double>::digits10 + 1) << timestamp << " "
-    << pose(0, 3) << " " << pose(1, 3) << " " << pose(2, 3) << " "
-    << q.x() << " " << q.y() << " " << q.z() << " " << q.w() << std::endl;
+  char line[256];
+  if (phovo_trajectory_format_pose(timestamp, pose.data(), line, sizeof(line)) != PHOVO_OK) return false;
+  f << line << std::endl;                                                    // :240-243
+  return true;
 }
 
 static void printHelp()
@@ -160,8 +160,9 @@ int main(int argc, char *argv[])
         std::cout << "Time = " << std::chrono::duration<double>(t1 - t0).count() << " sec." << std::endl;
 
         const Matrix44Type Rt = odometry.GetOptimalRigidTransformationMatrix();
-        pose *= Rt.inverse();                                                // :233-234
-        writePose(trajectoryFile, rgb[t].timestamp, pose);
+        const Vector6Type state = odometry.GetOptimalStateVector();
+        PHOVO_OK_OR_FAIL(phovo_trajectory_chain(1, state.data(), pose.data(), nullptr));   // pose *= Rt^-1  :233-234
+        if (!writePose(trajectoryFile, rgb[t].timestamp, pose)) return EXIT_FAILURE;
         std::cout << "Rt:" << std::endl << Rt << std::endl;
         prevGray = curGray.clone();
         prevDepth = curDepth.clone();
@@ -202,13 +203,12 @@ int main(int argc, char *argv[])
       PHOVO_OK_OR_FAIL(phovo_engine_align_pairs(engine, nPairs, src.data(), tgt.data(), nullptr, states.data(), nullptr));
       const auto t1 = std::chrono::steady_clock::now();
       std::cout << "Time = " << std::chrono::duration<double>(t1 - t0).count() << " sec. (" << nPairs << " pairs)" << std::endl;
+      std::vector<double> poses((size_t)nPairs * 16);
+      PHOVO_OK_OR_FAIL(phovo_trajectory_chain(nPairs, states.data(), pose.data(), poses.data()));
       for (int p = 0; p < nPairs; p++) {
-        double rt[16];
-        phovo_eigen_pose(&states[(size_t)p * 6], rt);
-        Matrix44Type Rt;
-        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) Rt(i, j) = rt[4 * i + j];
-        pose *= Rt.inverse();
-        writePose(trajectoryFile, rgb[(size_t)p + 1].timestamp, pose);
+        Matrix44Type P;
+        for (int i = 0; i < 16; i++) P(i) = poses[(size_t)p * 16 + i];
+        if (!writePose(trajectoryFile, rgb[(size_t)p + 1].timestamp, P)) return EXIT_FAILURE;
       }
       phovo_engine_destroy(engine);
     }

@@ -127,6 +127,19 @@ int phovo_extensions_read_file(const char *path, phovo_extensions *ext);
 /* eigenPose, CPhotoconsistencyOdometry.h:47-71: (x,y,z,yaw,pitch,roll) -> row-major 4x4. */
 int phovo_eigen_pose(const double state[6], double rt[16]);
 
+/* The VisualOdometry app's pose chain and trajectory line
+ * (apps/PhotoconsistencyVisualOdometry/PhotoconsistencyVisualOdometry.cpp:233-243):
+ *   pose *= Rt^-1 per pair, starting from `pose_io` (row-major 4x4; identity at the start of a sequence), with
+ *   Rt = eigenPose(states[p]); poses_out[p] (may be NULL) receives the pose after pair p, pose_io the last one.
+ * Host arithmetic only (no GPU): one implementation shared by the app's loop, its --batch path and the sharded
+ * sequence driver, so that their trajectory files are byte-identical. */
+int phovo_trajectory_chain(int n_pairs, const double *states /* [n_pairs][6] */, double pose_io[16],
+                           double *poses_out /* [n_pairs][16] or NULL */);
+/* `timestamp tx ty tz qx qy qz qw` with digits10 + 1 = 16 significant digits (:240-243), quaternion from the
+ * rotation block as Eigen::Quaternion(Matrix3) builds it (:237); no newline.  Returns PHOVO_E_INVALID_ARGUMENT if
+ * `capacity` is too small (256 always suffices). */
+int phovo_trajectory_format_pose(double timestamp, const double pose[16], char *line, size_t capacity);
+
 /* warpImage, CPhotoconsistencyOdometry.h:73-134 -- the forward warp both reference apps call after Optimize()
  * (...FrameAlignment.cpp:108, ...VisualOdometry.cpp:248-250) to show |I1 - warp(I0)|.  Host buffers in and out,
  * strides in bytes; rt row-major 4x4, k row-major 3x3, level scales the intrinsics by 2^-level as the reference does.

@@ -47,16 +47,45 @@ def scharr(img, scale):
     return gx, gy
 
 
-def build_pyramids(gray0, depth0, gray1, num_levels, grad_scale):
-    i0 = gray0.astype(np.float64) * (1.0 / 255)
-    i1 = gray1.astype(np.float64) * (1.0 / 255)
+def gaussian_blur_twice(img, ksize):
+    """cv::GaussianBlur(img, img, Size(k, k), 3) twice (...Analytic.h:146-147): separable, kernel
+    exp(-(i - (k-1)/2)^2 / (2*3^2)) normalised, BORDER_REFLECT_101 (scipy's "mirror")."""
+    if ksize <= 1:
+        return img.copy()
+    from scipy.ndimage import correlate1d
+    x = np.arange(ksize) - (ksize - 1) * 0.5
+    k = np.exp(-0.5 / 9.0 * x * x)
+    k /= k.sum()
+    out = img
+    for _ in range(2):
+        out = correlate1d(correlate1d(out, k, axis=1, mode="mirror"), k, axis=0, mode="mirror")
+    return out
+
+
+def intensity_pyramid(gray, num_levels, blur=None):
+    """BuildPyramid(intensity, applyBlur = true) (:115-163).  Level 0 is a shallow alias of the converted image
+    (`imgAux = img`, :136) and is blurred in place, so with blur[0] > 0 the later levels are resized from the
+    blurred image, then blurred with their own filter size."""
+    img = gray.astype(np.float64) * (1.0 / 255)
+    pyr = []
+    for l in range(num_levels):
+        lv = resize_level(img, l)
+        if blur is not None and blur[l] > 0:
+            lv = gaussian_blur_twice(lv, int(blur[l]))
+            if l == 0:
+                img = lv
+        pyr.append(lv)
+    return pyr
+
+
+def build_pyramids(gray0, depth0, gray1, num_levels, grad_scale, blur=None):
+    p0 = intensity_pyramid(gray0, num_levels, blur)
+    p1 = intensity_pyramid(gray1, num_levels, blur)
     out = []
     for l in range(num_levels):
-        a = resize_level(i0, l)
         d = resize_level(depth0.astype(np.float64), l)
-        b = resize_level(i1, l)
-        gx, gy = scharr(b, grad_scale[l])
-        out.append((a, d, b, gx, gy))
+        gx, gy = scharr(p1[l], grad_scale[l])
+        out.append((p0[l], d, p1[l], gx, gy))
     return out
 
 

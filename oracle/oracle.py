@@ -165,30 +165,36 @@ def scharr(img, scale):
     return gx, gy
 
 
-def build_source_pyramids(gray_u8, depth, cfg):
-    """SetSourceFrame (...Analytic.h:466-476): intensity (blurred if configured) and depth pyramids."""
-    i0 = convert_intensity(gray_u8)
-    ipyr, dpyr = [], []
-    depth = _f64(depth)
+def _intensity_pyramid(gray_u8, cfg):
+    """BuildPyramid(intensity, applyBlur = true) (...Analytic.h:115-163).  Level 0 is `imgAux = img` (:136), a shallow
+    cv::Mat alias of the converted image, and cv::GaussianBlur(imgAux, imgAux) (:146-147) writes through it: with
+    blurFilterSize[0] > 0 the image every later cv::resize(img, ...) (:132) reads is the BLURRED level 0.  (All
+    shipped configurations have blurFilterSize = 0; parity unpinned -- OpenCV is not in this image.)"""
+    img = convert_intensity(gray_u8)
+    pyr = []
     for level in range(cfg.num_levels):
-        lv = resize_level(i0, level)
+        lv = resize_level(img, level) if level else img
         if cfg.blur_filter_size[level] > 0:
             lv = gaussian_blur_twice(lv, cfg.blur_filter_size[level])
-        ipyr.append(lv)
-        dpyr.append(resize_level(depth, level))
-    return ipyr, dpyr
+            if level == 0:
+                img = lv                                   # the in-place blur of the aliased level 0
+        pyr.append(lv)
+    return pyr
+
+
+def build_source_pyramids(gray_u8, depth, cfg):
+    """SetSourceFrame (...Analytic.h:466-476): intensity (blurred if configured) and depth pyramids
+    (depth: applyBlur = false, :475, so the caller's image is never written)."""
+    depth = _f64(depth)
+    return _intensity_pyramid(gray_u8, cfg), [resize_level(depth, level) for level in range(cfg.num_levels)]
 
 
 def build_target_pyramids(gray_u8, cfg):
     """SetTargetFrame (...Analytic.h:479-491): intensity pyramid and its Scharr gradients."""
-    i1 = convert_intensity(gray_u8)
-    ipyr, gxp, gyp = [], [], []
-    for level in range(cfg.num_levels):
-        lv = resize_level(i1, level)
-        if cfg.blur_filter_size[level] > 0:
-            lv = gaussian_blur_twice(lv, cfg.blur_filter_size[level])
+    ipyr = _intensity_pyramid(gray_u8, cfg)
+    gxp, gyp = [], []
+    for level, lv in enumerate(ipyr):
         gx, gy = scharr(lv, cfg.image_gradients_scaling_factor[level])
-        ipyr.append(lv)
         gxp.append(gx)
         gyp.append(gy)
     return ipyr, gxp, gyp

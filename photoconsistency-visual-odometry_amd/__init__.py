@@ -12,7 +12,7 @@ __all__ = ["se3", "synthetic", "odometry", "native"]
 
 
 def __getattr__(name):
-    if name in ("odometry", "native", "distributed"):
+    if name in ("odometry", "native", "distributed", "sequence"):
         import importlib
         return importlib.import_module(f"{__name__}.{name}")
     raise AttributeError(name)

@@ -69,6 +69,7 @@ struct phovo_engine {
   double *d_depth = nullptr;
   uint16_t *d_depth16 = nullptr;
   double *d_tmp = nullptr;
+  double *d_blur0 = nullptr;                   // blurFilterSize[0] > 0: the blurred level-0 intensity of a staging chunk (see build_pyramids)
   double *d_scratch = nullptr;                 // fp64 planes of one staging chunk (narrow storages, plane get/set)
   double *d_blur_kernel = nullptr;             // [levels][max ksize]
   int blur_kernel_stride = 0;
@@ -109,7 +110,8 @@ void free_pool(phovo_engine *e)
   if (e->d_tmp) (void)hipFree(e->d_tmp);
   if (e->d_blur_kernel) (void)hipFree(e->d_blur_kernel);
   if (e->d_scratch) (void)hipFree(e->d_scratch);
-  e->d_scratch = nullptr;
+  if (e->d_blur0) (void)hipFree(e->d_blur0);
+  e->d_scratch = nullptr; e->d_blur0 = nullptr;
   e->d_gray = nullptr; e->d_depth = nullptr; e->d_depth16 = nullptr; e->d_tmp = nullptr;
   e->d_blur_kernel = nullptr;
   e->stage_frames = 0; e->stage_has_f64 = e->stage_has_u16 = false;
@@ -212,9 +214,11 @@ int ensure_stage(phovo_engine *e, int frames, bool want_f64, bool want_u16)
     if (e->d_gray) (void)hipFree(e->d_gray);
     if (e->d_depth) (void)hipFree(e->d_depth);
     if (e->d_depth16) (void)hipFree(e->d_depth16);
-    e->d_gray = nullptr; e->d_depth = nullptr; e->d_depth16 = nullptr;
+    if (e->d_blur0) (void)hipFree(e->d_blur0);
+    e->d_gray = nullptr; e->d_depth = nullptr; e->d_depth16 = nullptr; e->d_blur0 = nullptr;
     e->stage_frames = 0; e->stage_has_f64 = e->stage_has_u16 = false;
     PHOVO_HIP_CHECK(hipMalloc(&e->d_gray, px * (size_t)cap));
+    if (e->cfg.blur_filter_size[0] > 0) PHOVO_HIP_CHECK(hipMalloc(&e->d_blur0, px * (size_t)cap * sizeof(double)));
     if (want_f64) PHOVO_HIP_CHECK(hipMalloc(&e->d_depth, px * (size_t)cap * sizeof(double)));
     if (want_u16) PHOVO_HIP_CHECK(hipMalloc(&e->d_depth16, px * (size_t)cap * sizeof(uint16_t)));
     e->stage_frames = cap; e->stage_has_f64 = want_f64; e->stage_has_u16 = want_u16;
@@ -229,6 +233,18 @@ int build_pyramids(phovo_engine *e, int first_frame, int count, int roles, Depth
   const int w = e->width, h = e->height;
   const size_t px = (size_t)w * (size_t)h;
   const int storage = e->ext.plane_storage;
+  // blurFilterSize[0] > 0: the converted level-0 image, blurred twice, is the image every other level is resized from
+  // (whether or not level 0 itself is resident)
+  const double *blurred0 = nullptr;
+  if (e->cfg.blur_filter_size[0] > 0) {
+    const int ks0 = e->cfg.blur_filter_size[0];
+    PHOVO_HIP_CHECK(pyr_intensity_level(e->d_gray, px, count, w, h, 0, w, h, e->d_blur0, px, e->stream));   // convertTo  :471,484
+    for (int f = 0; f < count; f++) {
+      PHOVO_HIP_CHECK(pyr_gaussian_blur(e->d_blur0 + (size_t)f * px, e->d_tmp, w, h, ks0, e->d_blur_kernel, e->stream));
+      PHOVO_HIP_CHECK(pyr_gaussian_blur(e->d_blur0 + (size_t)f * px, e->d_tmp, w, h, ks0, e->d_blur_kernel, e->stream));
+    }
+    blurred0 = e->d_blur0;
+  }
   for (int l = 0; l < e->cfg.num_levels; l++) {
     LevelPool &lv = e->levels[l];
     if (!lv.stored) continue;
@@ -239,11 +255,19 @@ int build_pyramids(phovo_engine *e, int first_frame, int count, int roles, Depth
                        ? reinterpret_cast<double *>(lv.planes + (size_t)first_frame * lv.frame_bytes)
                        : e->d_scratch;
     // BuildPyramid(intensity, applyBlur = true)  :474,487
-    PHOVO_HIP_CHECK(pyr_intensity_level(e->d_gray, px, count, w, h, l, lv.w, lv.h,
-                                        base + (size_t)PLANE_I * lv.n, fstride, e->stream));
     const int ks = e->cfg.blur_filter_size[l];
-    if (ks > 0) {                                                       // GaussianBlur twice  :144-148
-      const double *kern = e->d_blur_kernel + (size_t)l * e->blur_kernel_stride;
+    const double *kern = ks > 0 ? e->d_blur_kernel + (size_t)l * e->blur_kernel_stride : nullptr;
+    if (blurred0) {
+      // Level 0 was blurred IN PLACE (`imgAux = img` is a shallow cv::Mat alias, :136, and GaussianBlur(imgAux, imgAux)
+      // writes through it, :146-147), so every cv::resize(img, ...) of the later levels (:132) reads the blurred
+      // level 0 (blurred0, made before this loop); level 0 itself is that image, not blurred a second time.
+      PHOVO_HIP_CHECK(pyr_depth_level(blurred0, px, count, w, h, l, lv.w, lv.h, base + (size_t)PLANE_I * lv.n, fstride,
+                                      e->stream));
+    } else {
+      PHOVO_HIP_CHECK(pyr_intensity_level(e->d_gray, px, count, w, h, l, lv.w, lv.h,
+                                          base + (size_t)PLANE_I * lv.n, fstride, e->stream));
+    }
+    if (ks > 0 && !(blurred0 && l == 0)) {                              // GaussianBlur twice  :144-148
       for (int f = 0; f < count; f++) {
         double *pi = base + (size_t)f * fstride + (size_t)PLANE_I * lv.n;
         PHOVO_HIP_CHECK(pyr_gaussian_blur(pi, e->d_tmp, lv.w, lv.h, ks, kern, e->stream));
@@ -565,7 +589,9 @@ int phovo_engine_reserve_frames(phovo_engine *e, int n_frames, int width, int he
     he = hipMalloc(&e->d_scratch, sizeof(double) * frames * PLANES_PER_FRAME * (max_n ? max_n : 1));
   }
   if (he == hipSuccess && max_ks > 0) {
-    he = hipMalloc(&e->d_tmp, sizeof(double) * (max_n ? max_n : 1));
+    // (a level-0 blur runs at full resolution even when level 0 is not resident)
+    const size_t tmp_n = e->cfg.blur_filter_size[0] > 0 ? (size_t)width * (size_t)height : max_n;
+    he = hipMalloc(&e->d_tmp, sizeof(double) * (tmp_n ? tmp_n : 1));
     if (he == hipSuccess) he = hipMalloc(&e->d_blur_kernel, sizeof(double) * (size_t)max_ks * PHOVO_MAX_LEVELS);
     if (he == hipSuccess) {
       // getGaussianKernel(k, sigma = 3, CV_64F): exp(-0.5/sigma^2 * (i-(k-1)/2)^2), normalised.

@@ -72,6 +72,8 @@ SYMBOLS = {
     "phovo_extensions_default": (C.c_int, [C.POINTER(Extensions)]),
     "phovo_extensions_read_file": (C.c_int, [C.c_char_p, C.POINTER(Extensions)]),
     "phovo_eigen_pose": (C.c_int, [_dp, _dp]),
+    "phovo_trajectory_chain": (C.c_int, [C.c_int, _vp, _dp, _vp]),
+    "phovo_trajectory_format_pose": (C.c_int, [C.c_double, _dp, C.c_char_p, C.c_size_t]),
     "phovo_warp_image": (C.c_int, [C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int, C.c_int, _dp, _dp, C.c_int,
                                    _vp, C.c_size_t]),
     "phovo_odometry_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),

@@ -111,3 +111,19 @@ def make_sequence(seed, n_frames, width=640, height=480, holes=0.0, trans=0.02, 
     motions = np.stack([poses[t + 1] @ np.linalg.inv(poses[t]) for t in range(n_frames - 1)]) \
         if n_frames > 1 else np.zeros((0, 4, 4))
     return dict(gray=np.stack(grays), depth=np.stack(depths), K=K, poses=poses, motions=motions)
+
+
+def half_pixel_problem(w=64, h=48, sign=1.0):
+    """A single-level problem whose projected coordinates are EXACTLY c + 0.5 / r + 0.5 in fp64: focal length 64 (a
+    power of two), integer principal point, depth 1.0 everywhere, zero rotation, initial translation
+    (0.5/64, 0.5/64, 0) * sign.  Every product and sum on the way (...Analytic.h:282-296) is exact, in the reference's
+    operation order and in the device's fused one alike, so C round() (:297-298) sees exact halves: half away from zero
+    sends (c + 0.5, r + 0.5) to (c + 1, r + 1), and (c - 0.5, r - 0.5) to (c, r) for c, r >= 1 but -0.5 to -1, i.e. out
+    of bounds (:302-303).  Returns (K, I0, D0, I1, initial state); random intensities, seeded."""
+    rs = np.random.RandomState(99)
+    K = np.array([[64.0, 0, float(w // 2)], [0, 64.0, float(h // 2)], [0, 0, 1.0]])
+    i0 = rs.uniform(0.1, 0.9, size=(h, w))
+    i1 = rs.uniform(0.1, 0.9, size=(h, w))
+    d0 = np.ones((h, w))
+    state = np.array([sign * 0.5 / 64.0, sign * 0.5 / 64.0, 0.0, 0.0, 0.0, 0.0])
+    return K, i0, d0, i1, state

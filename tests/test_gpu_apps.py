@@ -135,3 +135,34 @@ def test_apps_report_usage_and_missing_inputs(tmp_path):
     r = subprocess.run([os.path.join(BIN, "PhotoconsistencyVisualOdometry"), CFG5, str(tmp_path / "nope"), str(tmp_path / "t.txt")],
                        capture_output=True, text=True)
     assert r.returncode != 0 and "does not exist" in r.stderr
+
+
+def test_frame_alignment_app_with_config_only_level_0_as_shipped(tmp_path):
+    """BASELINE.json configs[0] literally: PhotoconsistencyFrameAlignment + config_only_level_0_analytic.yml (one level
+    of 307 200 pixels, max 5000 iterations, min gradient norm 300, visualizeIterations: 1 -- which would open imshow
+    windows in the reference, config_files/config_only_level_0_analytic.yml:6-8, ...Analytic.h:551-557, and is ignored
+    headless) on a synthetic 640x480 pair written as PNGs (depth / 1000, ...FrameAlignment.cpp:76,80): iterations and Rt
+    against the oracle on the decoded inputs."""
+    cfg0 = os.path.join(ROOT, "config_files", "config_only_level_0_analytic.yml")
+    p = synthetic.make_pair(17, 640, 480, holes=0.02, trans=0.006, rot=0.003)
+    d16 = [np.rint(p[f"depth{i}"] * 1000.0).astype(np.uint16) for i in (0, 1)]
+    for i in (0, 1):
+        Image.fromarray(p[f"gray{i}"]).save(tmp_path / f"g{i}.png")
+        Image.fromarray(d16[i]).save(tmp_path / f"d{i}.png")
+    ocfg = _oracle_cfg(cfg0)
+    assert ocfg.num_levels == 1 and ocfg.max_num_iterations[0] == 5000 and ocfg.min_gradient_norm[0] == 300.0
+    es, eits = oracle.align_frames(ocfg, K_FA, p["gray0"], d16[0].astype(np.float64) * (1.0 / 1000.0), p["gray1"])
+    assert 1 < eits[0] < 5000                                        # stops on the gradient threshold, after several passes
+    env = dict(os.environ, PHOVO_PRINT_OPTIMIZATION_PROGRESS="1")
+    r = subprocess.run([os.path.join(BIN, "PhotoconsistencyFrameAlignment"), cfg0, str(tmp_path / "g0.png"),
+                        str(tmp_path / "d0.png"), str(tmp_path / "g1.png"), str(tmp_path / "d1.png")],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    assert re.search(r"Time = [0-9.e+-]+ sec\.", r.stdout)
+    m = re.search(r"Optimization level: 0\nNumber iterations: (\d+)\ngradient norm: ([0-9.e+-]+)", r.stdout)
+    assert m, r.stdout
+    assert int(m.group(1)) == eits[0]
+    assert float(m.group(2)) < 300.0
+    body = r.stdout.split("main::Rt eigen:")[1].strip().split("\n")[:4]
+    Rt = np.array([[float(v) for v in row.split()] for row in body])
+    np.testing.assert_allclose(Rt, se3.eigen_pose(es), atol=1e-5)    # default ostream precision: 6 digits

@@ -100,19 +100,42 @@ def test_device_pyramids_bit_exact(size):
             np.testing.assert_array_equal(gy, gyp[l])
 
 
-def test_device_gaussian_blur_bit_exact():
+@pytest.mark.parametrize("blur,build_all", [([5, 3, 0], True), ([5, 3, 0], False), ([0, 3, 5], True), ([1, 0, 7], True)])
+def test_device_gaussian_blur_bit_exact(blur, build_all):
+    """GaussianBlur twice where blurFilterSize > 0 (...Analytic.h:144-148), including the level-0 alias: `imgAux = img`
+    (:136) is shallow, so a level-0 blur is in place and the later levels are resized from the BLURRED image -- also
+    when level 0 itself is not resident (max_num_iterations[0] == 0).  Batched and per-frame uploads, both roles."""
     p = synthetic.make_pair(8, 160, 120)
     nl = 3
-    ncfg, ocfg = _cfgs(nl, [1] * nl, [0] * nl, blur=[5, 3, 0])
+    max_iter = [1] * nl if build_all else [0, 1, 1]
+    ncfg, ocfg = _cfgs(nl, max_iter, [0] * nl, blur=blur)
     i1p, gxp, gyp = oracle.build_target_pyramids(p["gray1"], ocfg)
+    i0p, d0p = oracle.build_source_pyramids(p["gray0"], p["depth0"], ocfg)
     with odometry.AlignmentEngine() as eng:
         eng.set_config(ncfg)
-        eng.reserve_frames(1, 160, 120)
+        eng.reserve_frames(4, 160, 120)
         eng.upload_frame(0, p["gray1"], p["depth1"])
+        eng.upload_frames(1, np.stack([p["gray0"], p["gray1"], p["gray0"]]),
+                          np.stack([p["depth0"], p["depth1"], p["depth0"]]))
         for l in range(nl):
-            i1, _, gx, gy = eng.get_level_planes(0, l)
-            np.testing.assert_array_equal(i1, i1p[l])
-            np.testing.assert_array_equal(gx, gxp[l])
+            if not eng.level_is_stored(l):
+                assert not build_all and l == 0
+                continue
+            for f in (0, 2):
+                i1, _, gx, gy = eng.get_level_planes(f, l)
+                np.testing.assert_array_equal(i1, i1p[l])
+                np.testing.assert_array_equal(gx, gxp[l])
+                np.testing.assert_array_equal(gy, gyp[l])
+            for f in (1, 3):
+                i0, d0, _, _ = eng.get_level_planes(f, l)
+                np.testing.assert_array_equal(i0, i0p[l])
+                np.testing.assert_array_equal(d0, d0p[l])
+        # and the alignment on those planes agrees with the oracle's
+        eng.set_intrinsic_matrix(p["K"])
+        s, reps = eng.align_pairs([1], [2], want_reports=True)
+    es, eits = oracle.align_frames(ocfg, p["K"], p["gray0"], p["depth0"], p["gray1"])
+    assert list(reps[0].iterations[:nl]) == eits
+    assert se3.state_distance(s[0], es) < POSE_TOL
 
 
 def test_u16_depth_upload_matches_scaled_double():
@@ -594,6 +617,33 @@ def test_work_queue_results_do_not_depend_on_position_or_history(yml, fixed):
             assert np.array_equal(states[pos], states[first[i]]), (pos, i)
             assert list(reps[pos].iterations[:nl]) == list(reps[first[i]].iterations[:nl])
         assert reps[pos].flags == 0
+
+
+@pytest.mark.parametrize("sign", [1.0, -1.0])
+@pytest.mark.parametrize("size,pairs", [((64, 48), 1), ((64, 48), 9), ((192, 128), 9), ((320, 240), 40)])
+def test_exact_half_pixel_projections_on_the_device(sign, size, pairs):
+    """tests/test_oracle_properties.py::half_pixel_problem on the device: every projected coordinate is an exact half
+    (c +- 0.5, r +- 0.5), where C round() -- half away from zero, ...Analytic.h:297-298 -- decides the target pixel of
+    EVERY source pixel at once.  The device path differs from the oracle in how it gets there (v_rcp_f64 + Newton for
+    1/Z, fused Rt*p, a 5-instruction round for arguments above -0.5: DESIGN.md section 4); on these inputs all of that is
+    exact, so the first Gauss-Newton step must match the oracle's to the usual bar -- a half rounded the other way
+    would pair every residual with the wrong pixel.  One geometry per launch form (TINY / QUAD+MID latency / WIDE / HUGE)."""
+    w, h = size
+    K, i0, d0, i1, state = synthetic.half_pixel_problem(w, h, sign)
+    gx, gy = oracle.scharr(i1, 0.0625)
+    ncfg, ocfg = _cfgs(1, [1], [0.0])
+    es, eits = oracle.optimize(ocfg, K, [i0], [d0], [i1], [gx], [gy], init_state=state)
+    assert eits == [1] and np.all(np.isfinite(es)) and np.linalg.norm(es - state) > 1e-6
+    with odometry.AlignmentEngine() as eng:
+        eng.set_config(ncfg)
+        eng.set_intrinsic_matrix(K)
+        eng.reserve_frames(2, w, h)
+        eng.set_level_planes(0, 0, intensity=i0, depth=d0)
+        eng.set_level_planes(1, 0, intensity=i1, grad_x=gx, grad_y=gy)
+        s, reps = eng.align_pairs([0] * pairs, [1] * pairs, init_states=np.tile(state, (pairs, 1)), want_reports=True)
+    for k in range(pairs):
+        assert list(reps[k].iterations[:1]) == [1] and reps[k].flags == 0
+        assert se3.state_distance(s[k], es) < POSE_TOL, (k, se3.state_distance(s[k], es))
 
 
 def test_randomised_sweep_against_oracle():

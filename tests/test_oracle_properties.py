@@ -131,3 +131,66 @@ def test_warp_image_truncates_and_gates_on_positive_depth():
     rt[0, 3] = 1.0
     out = oracle.warp_image(g, d, rt, K)
     assert list(out[0]) == [0, 10, 0, 30]
+
+
+def test_level_zero_blur_is_in_place_and_feeds_the_later_levels():
+    """BuildPyramid: `imgAux = img` (...Analytic.h:136) is a shallow cv::Mat alias, so GaussianBlur(imgAux, imgAux)
+    (:146-147) blurs the converted image itself and every later cv::resize(img, ...) (:132) reads the blurred
+    level 0.  Oracle against the independent twin (scipy separable correlation), and against the naive reading
+    (resize from the unblurred image), which must differ.  Parity unpinned: OpenCV is not in this image and every
+    shipped configuration has blurFilterSize = 0."""
+    p = synthetic.make_pair(12, 160, 120)
+    blur = [5, 3, 0]
+    cfg = oracle.make_config(num_levels=3, blur=blur, max_iter=[1, 1, 1], min_grad=[0, 0, 0])
+    i1p, gxp, gyp = oracle.build_target_pyramids(p["gray1"], cfg)
+    i0p, d0p = oracle.build_source_pyramids(p["gray0"], p["depth0"], cfg)
+    tp = twin.intensity_pyramid(p["gray1"], 3, blur)
+    for l in range(3):
+        np.testing.assert_allclose(i1p[l], tp[l], rtol=0, atol=1e-14)
+        gx, gy = twin.scharr(tp[l], 0.0625)
+        np.testing.assert_allclose(gxp[l], gx, rtol=0, atol=1e-13)
+    raw = oracle.convert_intensity(p["gray1"])
+    # level 0: blurred once (twice the filter, not four times); level 1: resize OF the blurred level 0, then its own blur
+    np.testing.assert_array_equal(i1p[0], oracle.gaussian_blur_twice(raw, 5))
+    np.testing.assert_array_equal(i1p[1], oracle.gaussian_blur_twice(oracle.resize_level(i1p[0], 1), 3))
+    np.testing.assert_array_equal(i1p[2], oracle.resize_level(i1p[0], 2))
+    naive1 = oracle.gaussian_blur_twice(oracle.resize_level(raw, 1), 3)
+    assert np.max(np.abs(naive1 - i1p[1])) > 1e-4
+    # depth is built with applyBlur = false (:475): never blurred
+    np.testing.assert_array_equal(d0p[1], oracle.resize_level(p["depth0"], 1))
+    # blur only at a later level: level 0 untouched, later levels resized from the raw image
+    cfg2 = oracle.make_config(num_levels=3, blur=[0, 3, 0], max_iter=[1, 1, 1], min_grad=[0, 0, 0])
+    j1p, _, _ = oracle.build_target_pyramids(p["gray1"], cfg2)
+    np.testing.assert_array_equal(j1p[0], raw)
+    np.testing.assert_array_equal(j1p[2], oracle.resize_level(raw, 2))
+
+
+def half_pixel_problem(w=64, h=48, sign=1.0):
+    K, i0, d0, i1, state = synthetic.half_pixel_problem(w, h, sign)
+    gx, gy = twin.scharr(i1, 0.0625)
+    return K, i0, d0, i1, gx, gy, state
+
+
+def test_exact_half_pixel_projections_round_half_away_from_zero():
+    """Known answer for the rounding rule the whole scatter hangs on: with every projection on an exact half, the
+    residual slot of target (r + 1, c + 1) holds I1(r + 1, c + 1) - I0(r, c) (positive halves round up), and with the
+    sign flipped target (r, c) holds I1(r, c) - I0(r, c) except in row 0 / column 0, whose sources project to -0.5,
+    round to -1 and are dropped."""
+    K, i0, d0, i1, gx, gy, state = half_pixel_problem()
+    h, w = i0.shape
+    r, J = oracle.compute_residuals_and_jacobians(i0, d0, i1, gx, gy, 0, K, state)
+    r = r.reshape(h, w)
+    np.testing.assert_array_equal(r[1:, 1:], i1[1:, 1:] - i0[:-1, :-1])
+    assert np.all(r[0, :] == 0) and np.all(r[:, 0] == 0)
+    J = J.reshape(6, h, w)
+    assert np.all(J[:, -1, :] == 0) and np.all(J[:, :, -1] == 0)         # last row / column project out of bounds
+    assert np.all(np.any(J[:, 1:-1, 1:-1] != 0, axis=0))               # (row 0 / column 0: the reflected Scharr gradient can be 0)
+    K, i0, d0, i1, gx, gy, state = half_pixel_problem(sign=-1.0)
+    r, J = oracle.compute_residuals_and_jacobians(i0, d0, i1, gx, gy, 0, K, state)
+    r, J = r.reshape(h, w), J.reshape(6, h, w)
+    np.testing.assert_array_equal(r[1:, 1:], i1[1:, 1:] - i0[1:, 1:])
+    assert np.all(r[0, :] == 0) and np.all(r[:, 0] == 0)                 # round(-0.5) = -1: out of bounds
+    assert np.all(J[:, 0, :] == 0) and np.all(J[:, :, 0] == 0)
+    # the twin (np.sign * floor(|x| + 0.5)) agrees
+    g, H, rt, Jt = twin.normal_equations((i0, d0, i1, gx, gy), 0, K, state)
+    np.testing.assert_allclose(rt.reshape(h, w), r, atol=0)

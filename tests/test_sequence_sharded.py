@@ -1,0 +1,180 @@
+"""One sequence, sharded: photoconsistency-visual-odometry_amd/sequence.py and apps/PhotoconsistencyVisualOdometrySharded.py
+(reference loop: apps/PhotoconsistencyVisualOdometry/PhotoconsistencyVisualOdometry.cpp:175,208-243).
+
+CPU tests: the host logic -- list reading in lock step, the apps' PNG decoder behind its C ABI, the shared pose chain /
+line formatter, and a world-size-2 gloo launch that runs up to the device check (each rank decodes only its frames, then
+fails loudly: there is no CPU path).  The GPU test runs the whole thing on a 601-frame sequence with the ranks sharing
+the card and compares the trajectory file byte for byte with the single-process C++ app."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+from PIL import Image
+
+import phovo_amd  # noqa: F401
+from phovo_amd import distributed, native, se3, sequence, synthetic
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+APP = os.path.join(ROOT, "apps", "bin", "PhotoconsistencyVisualOdometry")
+SHARDED = os.path.join(ROOT, "apps", "PhotoconsistencyVisualOdometrySharded.py")
+CFG5 = os.path.join(ROOT, "config_files", "config_5_level_optimization_analytic.yml")
+
+
+def _clean_env(extra=None):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra or {})
+    return env
+
+
+def write_tum_sequence(root, n_frames, width=640, height=480, distinct=None, rgb_colour=True, extra_depth_lines=0):
+    """A TUM-layout directory: rgb/ + depth/ PNGs, rgb.txt, depth.txt.  `distinct` frames are rendered (a camera moving
+    through one synthetic scene) and then cycled forwards and backwards, so that 600 frames cost 40 renders; every frame
+    is still its own file."""
+    distinct = distinct or n_frames
+    K = sequence.K_TUM * (width / 640.0)
+    K[2, 2] = 1.0
+    scene = synthetic.Scene(21)
+    rs = np.random.RandomState(5)
+    T = np.eye(4)
+    os.makedirs(os.path.join(root, "rgb"))
+    os.makedirs(os.path.join(root, "depth"))
+    rendered = []
+    for f in range(distinct):
+        if f:
+            T = se3.eigen_pose(synthetic.random_motion(rs, 0.02, 0.01)) @ T
+        g, d = synthetic.render(scene, T, width, height, K, holes=0.01, hole_seed=f)
+        rendered.append((g, np.rint(d * 5000.0).astype(np.uint16)))
+    rgb_lines = ["# color images", "# file: synthetic", "# timestamp filename"]
+    dep_lines = ["# depth maps", "# file: synthetic", "# timestamp filename"]
+    period = max(2 * distinct - 2, 1)
+    for f in range(n_frames):
+        k = f % period
+        k = k if k < distinct else period - k                     # 0 1 .. d-1 d-2 .. 1 0 1 ..
+        g, d16 = rendered[k]
+        ts = 1305031102.175304 + 0.033 * f
+        if rgb_colour and f % 2 == 0:
+            rgb = np.stack([np.clip(g.astype(int) + 12, 0, 255), g, np.clip(g.astype(int) - 9, 0, 255)], axis=-1)
+            Image.fromarray(rgb.astype(np.uint8), "RGB").save(os.path.join(root, "rgb", f"{ts:.6f}.png"))
+        else:
+            Image.fromarray(g).save(os.path.join(root, "rgb", f"{ts:.6f}.png"))
+        Image.fromarray(d16).save(os.path.join(root, "depth", f"{ts + 0.01:.6f}.png"))
+        rgb_lines.append(f"{ts:.6f} rgb/{ts:.6f}.png")
+        dep_lines.append(f"{ts + 0.01:.6f} depth/{ts + 0.01:.6f}.png")
+    for e in range(extra_depth_lines):                               # lists of unequal length: lock step stops at the shorter
+        dep_lines.append(f"{1305039999.0 + e:.6f} depth/missing_{e}.png")
+    with open(os.path.join(root, "rgb.txt"), "w") as f:
+        f.write("\n".join(rgb_lines) + "\n")
+    with open(os.path.join(root, "depth.txt"), "w") as f:
+        f.write("\n".join(dep_lines) + "\n")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CPU: host logic
+# ---------------------------------------------------------------------------------------------------------------
+def test_lists_are_read_in_lock_step_and_stop_at_the_shorter(tmp_path):
+    write_tum_sequence(str(tmp_path), 5, 32, 24, extra_depth_lines=3)
+    rgb, depth = sequence.read_sequence_lists(str(tmp_path))
+    assert len(rgb) == len(depth) == 5                           # depth.txt has 8 entries
+    assert all(os.path.isabs(p) and os.path.exists(p) for _, p in rgb + depth)
+    assert abs(rgb[1][0] - (1305031102.175304 + 0.033)) < 1e-6
+    assert abs(depth[0][0] - rgb[0][0] - 0.01) < 1e-6            # no timestamp association: line n with line n
+
+
+def test_png_decoder_is_the_apps_one(tmp_path):
+    """libphovo_io.so: gray PNGs come back verbatim, colour ones through cv::imread(path, 0)'s fixed-point BGR2GRAY,
+    16-bit depth unchanged."""
+    rs = np.random.RandomState(0)
+    g = rs.randint(0, 256, size=(24, 32)).astype(np.uint8)
+    rgb = rs.randint(0, 256, size=(24, 32, 3)).astype(np.uint8)
+    d = rs.randint(0, 65536, size=(24, 32)).astype(np.uint16)
+    Image.fromarray(g).save(tmp_path / "g.png")
+    Image.fromarray(rgb, "RGB").save(tmp_path / "c.png")
+    Image.fromarray(d).save(tmp_path / "d.png")
+    np.testing.assert_array_equal(sequence.read_gray8(str(tmp_path / "g.png")), g)
+    np.testing.assert_array_equal(sequence.read_depth16(str(tmp_path / "d.png")), d)
+    r, gg, b = [rgb[..., i].astype(np.int64) for i in range(3)]
+    np.testing.assert_array_equal(sequence.read_gray8(str(tmp_path / "c.png")),
+                                  ((9797 * r + 19234 * gg + 3737 * b + 16384) >> 15).astype(np.uint8))
+    with pytest.raises(IOError):
+        sequence.read_gray8(str(tmp_path / "missing.png"))
+
+
+def test_shared_pose_chain_and_line_format_match_the_numpy_restatement():
+    """phovo_trajectory_chain / phovo_trajectory_format_pose (what the C++ app and the sharded driver both call)
+    against se3.chain_trajectory + format_trajectory: same numbers to 1e-12, 16 significant digits, chaining resumable."""
+    rs = np.random.RandomState(3)
+    states = np.concatenate([rs.uniform(-0.05, 0.05, size=(40, 3)), rs.uniform(-0.03, 0.03, size=(40, 3))], axis=1)
+    ts = 1305031102.175304 + 0.033 * np.arange(1, 41)
+    text = sequence.chain_and_format(states, ts)
+    lines = text.strip().split("\n")
+    assert lines[:2] == ["# estimated trajectory", "# timestamp tx ty tz qx qy qz qw"] and len(lines) == 42
+    poses = distributed.trajectory_from_states(states)
+    ref = distributed.format_trajectory(ts, poses).strip().split("\n")
+    for a, b in zip(lines[2:], ref[2:]):
+        fa, fb = [float(v) for v in a.split()], [float(v) for v in b.split()]
+        np.testing.assert_allclose(fa, fb, rtol=0, atol=1e-12)
+        assert a.split()[0] == b.split()[0]                      # the timestamp prints identically
+    # chaining in two calls == chaining in one (pose_io carries the state)
+    import ctypes as C
+    L = native.lib()
+    dp = C.POINTER(C.c_double)
+    pose = np.eye(4).reshape(16).copy()
+    one = np.zeros((40, 16))
+    L.phovo_trajectory_chain(40, states.ctypes.data, pose.ctypes.data_as(dp), one.ctypes.data)
+    pose2 = np.eye(4).reshape(16).copy()
+    two = np.zeros((40, 16))
+    L.phovo_trajectory_chain(15, states[:15].ctypes.data, pose2.ctypes.data_as(dp), two[:15].ctypes.data)
+    L.phovo_trajectory_chain(25, states[15:].ctypes.data, pose2.ctypes.data_as(dp), two[15:].ctypes.data)
+    assert np.array_equal(one, two) and np.array_equal(pose, pose2)
+    assert L.phovo_trajectory_format_pose(1.0, pose.ctypes.data_as(dp), C.create_string_buffer(8), 8) != 0
+
+
+def test_two_gloo_ranks_decode_only_their_shard_then_stop_at_the_device_check(tmp_path):
+    """World size 2 on the CPU: both ranks join, rank r decodes frames_needed(shard_range(F-1, 2, r)) only, and --
+    this container having no GPU -- both fail in phovo_engine_create instead of computing anything on the host."""
+    if native.lib().phovo_device_count() > 0:
+        pytest.skip("a GPU is present: covered by the gpu-marked test below")
+    write_tum_sequence(str(tmp_path / "seq"), 9, 64, 48)
+    out = tmp_path / "traj.txt"
+    r = subprocess.run([sys.executable, SHARDED, CFG5, str(tmp_path / "seq"), str(out), "--ranks", "2", "--backend", "gloo"],
+                       capture_output=True, text=True, timeout=600, env=_clean_env())
+    assert "starting 2 ranks" in r.stderr
+    assert "rank 0/2 joined the gloo group" in r.stderr and "rank 1/2 joined the gloo group" in r.stderr
+    assert "rank 0/2 decoded frames [0, 5) for pairs [0, 4)" in r.stderr
+    assert "rank 1/2 decoded frames [4, 9) for pairs [4, 8)" in r.stderr
+    assert r.returncode != 0 and "no HIP device available" in r.stderr
+    assert not out.exists()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GPU: the whole path on a sequence of BASELINE config 3's length
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_sharded_sequence_is_byte_identical_to_the_single_process_app(tmp_path):
+    """601 frames (600 pairs: the length of TUM fr1/desk, which is not on disk), 640x480, colour and gray PNGs, u16
+    depth, depth.txt longer than rgb.txt.  `PhotoconsistencyVisualOdometry --batch` in one process against the sharded
+    driver with 2 and with 3 gloo ranks sharing this box's GPU (uneven shards) and with one rank: byte-identical
+    trajectory files."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "apps")])
+    seq = tmp_path / "seq"
+    write_tum_sequence(str(seq), 601, distinct=40, extra_depth_lines=2)
+    ref = tmp_path / "ref.txt"
+    r = subprocess.run([APP, CFG5, str(seq), str(ref), "--batch"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    want = ref.read_bytes()
+    assert want.count(b"\n") == 2 + 600
+    for ranks in (2, 3, 1):
+        out = tmp_path / f"sharded_{ranks}.txt"
+        r = subprocess.run([sys.executable, SHARDED, CFG5, str(seq), str(out), "--ranks", str(ranks), "--backend", "gloo"],
+                           capture_output=True, text=True, timeout=900, env=_clean_env())
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert out.read_bytes() == want, ranks
+        if ranks == 3:
+            assert "rank 2/3 decoded frames [400, 601) for pairs [400, 600)" in r.stderr
+    # the poses are real: consecutive frames of the generator are a few centimetres apart
+    last = [float(v) for v in want.decode().strip().split("\n")[-1].split()]
+    assert np.isfinite(last).all() and abs(np.linalg.norm(last[4:8]) - 1.0) < 1e-9
