@@ -60,6 +60,9 @@ def parse():
                     help="plane storage (f64 = reference-exact; arithmetic is fp64 in every mode)")
     ap.add_argument("--huber", type=float, default=0.0, help="Huber delta on every level (0 = off)")
     ap.add_argument("--bilinear", action="store_true", help="bilinear forward-additive sampling + corrected Jacobian")
+    ap.add_argument("--max-iterations", default=None,
+                    help="diagnostic, never the default: comma list overriding the yml's max_num_iterations, level 0 first "
+                         "(e.g. 0,0,1,1 = every plane streamed exactly once: the HBM-only rate of the level kernels)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2",
                     help="cfg2 = the headline 640x480 4-level workload; cfg5 = BASELINE.json configs[4]'s shape "
                          "(1280x960, config_6_level; combine with --storage f16 --huber 0.05)")
@@ -195,8 +198,14 @@ def main():
     reps = (args.pairs + distinct - 1) // distinct
     cfg_ref = native.read_config_file(YML)
     nl = cfg_ref.num_levels
-    max_iter = list(cfg_ref.max_num_iterations[:nl])
     cfg_fixed = native.read_config_file(YML)
+    if args.max_iterations:
+        override = [int(v) for v in args.max_iterations.split(",")]
+        if len(override) != nl:
+            raise SystemExit(f"--max-iterations needs {nl} values for {wl['yml']}")
+        for l in range(nl):
+            cfg_ref.max_num_iterations[l] = cfg_fixed.max_num_iterations[l] = override[l]
+    max_iter = list(cfg_ref.max_num_iterations[:nl])
     for l in range(nl):
         cfg_fixed.min_gradient_norm[l] = 0.0
 
@@ -438,7 +447,8 @@ def main():
                             + " per pair), Optimize() only with pyramids resident in HBM",
                 "pairs_per_gpu": n_local, "global_pairs_per_step": n_global,
                 "distinct_pairs_per_gpu": distinct, "image": [W, H], "levels": nl,
-                "max_num_iterations": max_iter, "parallelism": f"pairs sharded x{world}, RCCL all_gather of states",
+                "max_num_iterations": max_iter, "max_num_iterations_overridden": bool(args.max_iterations),
+                "parallelism": f"pairs sharded x{world}, RCCL all_gather of states",
                 "all_gather_from_device_buffer": ZERO_COPY["ok"],
             },
             "iterations_per_pair": [float(x) for x in iters.mean(axis=0)],

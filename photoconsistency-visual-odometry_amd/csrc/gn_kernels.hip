@@ -745,7 +745,7 @@ static_assert((1 << OWNER_TAG_SHIFT) - 1 == OWNER_INDEX_MASK, "index mask and ta
 //   HUGE   1024 threads, owner map in global memory, ballot mask in LDS
 //   TINY   256 threads, 4 workgroups/CU, everything in LDS (levels of <= 2048 pixels)
 //   QUAD   256 threads, 4 workgroups/CU, owner map in LDS, source intensity gathered from L2
-enum Variant { V_TINY = 0, V_MID, V_WIDE, V_HUGE, V_QUAD };
+enum Variant { V_TINY = 0, V_MID, V_WIDE, V_HUGE, V_QUAD, V_DUO };
 
 // ... times the three plane storages (fp64 = reference-exact; fp32; fp16 images + fp32 depth).
 #define PHOVO_KERNEL_TINY(TI, TD)  gn_level_kernel<256, 4, true, true, true, TI, TD>
@@ -753,6 +753,7 @@ enum Variant { V_TINY = 0, V_MID, V_WIDE, V_HUGE, V_QUAD };
 #define PHOVO_KERNEL_WIDE(TI, TD)  gn_level_kernel<1024, 4, false, true, true, TI, TD>
 #define PHOVO_KERNEL_HUGE(TI, TD)  gn_level_kernel<1024, 4, false, false, false, TI, TD>
 #define PHOVO_KERNEL_QUAD(TI, TD)  gn_level_kernel<256, 4, false, true, true, TI, TD>
+#define PHOVO_KERNEL_DUO(TI, TD)   gn_level_kernel<512, 4, true, true, true, TI, TD>
 
 }  // namespace
 
@@ -773,6 +774,13 @@ bool gn_plan_level(int n, GNLaunchPlan *plan, bool prefer_latency)
   // PHOVO_GN_NO_QUAD=1 is a tuning aid for tools/ only.
   static const bool no_quad = std::getenv("PHOVO_GN_NO_QUAD") != nullptr;
   // (one pair alone on a CU: 12.4 us per 80x60 iteration with 256 threads, 10.1 us with 512 -- prefer_latency)
+  // experiment (tools/ only): two 512-thread workgroups per CU with the source intensity plane staged in LDS
+  static const bool duo = std::getenv("PHOVO_GN_DUO") != nullptr;
+  if (duo && !prefer_latency && n_chunks <= 64 * 8 && lds_fixed_bytes(512) + owner + src <= LDS_HALF) {
+    plan->variant = V_DUO; plan->threads = 512; plan->wgs_per_cu = 2; plan->owner_in_lds = true; plan->source_in_lds = true;
+    plan->lds_bytes = (int)(lds_fixed_bytes(512) + owner + src);
+    return true;
+  }
   if (!no_quad && !prefer_latency && n_chunks <= 64 * 4 && f256 + owner <= LDS_LIMIT / 4) {
     plan->variant = V_QUAD; plan->threads = 256; plan->wgs_per_cu = 4; plan->owner_in_lds = true; plan->source_in_lds = false;
     plan->lds_bytes = (int)(f256 + owner);
@@ -817,6 +825,7 @@ hipError_t prepare_storage()
   PHOVO_PREP(PHOVO_KERNEL_WIDE)
   PHOVO_PREP(PHOVO_KERNEL_HUGE)
   PHOVO_PREP(PHOVO_KERNEL_QUAD)
+  PHOVO_PREP(PHOVO_KERNEL_DUO)
 #undef PHOVO_PREP
   return hipSuccess;
 }
@@ -832,6 +841,7 @@ hipError_t launch_storage(const GNLevelArgs &a, const GNLaunchPlan &plan, int n_
     case V_WIDE:  hipLaunchKernelGGL(PHOVO_KERNEL_WIDE(TI, TD), grid, block, lds, stream, a); break;
     case V_HUGE:  hipLaunchKernelGGL(PHOVO_KERNEL_HUGE(TI, TD), grid, block, lds, stream, a); break;
     case V_QUAD:  hipLaunchKernelGGL(PHOVO_KERNEL_QUAD(TI, TD), grid, block, lds, stream, a); break;
+    case V_DUO:   hipLaunchKernelGGL(PHOVO_KERNEL_DUO(TI, TD), grid, block, lds, stream, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
