@@ -48,6 +48,10 @@ typedef enum phovo_status {
 #define PHOVO_PAIR_NONFINITE 1u  /* J^T J was singular / the state became inf or NaN: the reference
                                     propagates inf/NaN silently (...Analytic.h:540); so does this
                                     library, but it says so here.                                 */
+#define PHOVO_PAIR_WINDOW_FALLBACK 2u  /* informational: on a level whose owner map exceeds LDS this pair's warp left
+                                    the sliding window of the fast kernel (a displacement of more than ~12 000 pixels in
+                                    linear index, e.g. a large in-plane rotation) and the exact kernel with the map
+                                    in HBM finished it.  The result is the same; only the time differs.          */
 
 /* The per-level parameter vectors of the reference (...Analytic.h:91-103), as filled by
  * ReadConfigurationFile (:581-607) or by the constructor defaults (:430-443). */
@@ -201,6 +205,10 @@ int phovo_engine_set_build_all_levels(phovo_engine *e, int on);
  * a large level; reference-exact configuration only).  policy: 0 = automatic (wide iff n_pairs <= 32 and the level
  * has >= 16384 pixels), 1 = wide wherever possible, -1 = never.  Results are the same either way. */
 int phovo_engine_set_wide_policy(phovo_engine *e, int policy);
+/* Levels whose owner map exceeds LDS (more than ~39 k pixels) run the sliding-window kernel (owner ring in LDS) followed
+ * by the exact kernel (owner map in HBM) for the pairs whose warp left the window.  policy: 0 = automatic (that), -1 =
+ * exact kernel only.  Results are the same either way (tests/test_gpu_parity.py). */
+int phovo_engine_set_slide_policy(phovo_engine *e, int policy);
 /* 1 if `level` would run in the wide form for a batch of n_pairs under the current settings. */
 int phovo_engine_level_uses_wide(const phovo_engine *e, int level, int n_pairs);
 

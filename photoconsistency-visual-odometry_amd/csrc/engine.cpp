@@ -87,7 +87,9 @@ struct phovo_engine {
   int *d_owner = nullptr;
   size_t owner_capacity = 0;
   bool owner_tagged = false;                   // d_owner holds tagged entries of the persistent kernel, not the -1 the wide form expects
-  int *d_work_counters = nullptr;              // [PHOVO_MAX_LEVELS] work-queue heads of the level launches (view into d_pairs)
+  int *d_work_counters = nullptr;              // [2][PHOVO_MAX_LEVELS][QUEUES_PER_LEVEL] work-queue heads of the level launches (view into d_pairs)
+  int *d_resume = nullptr;                     // [pairs] marks of the sliding-window form (view into d_pairs)
+  int slide_policy = 0;                        // 0 automatic (where the owner map exceeds LDS), -1 never
   int cu_count = 256;
   void *d_wide_ws = nullptr;                   // workspace of the wide (many-workgroups-per-pair) level form
   size_t wide_ws_capacity = 0;
@@ -123,7 +125,7 @@ void free_pairs(phovo_engine *e)
   if (e->d_pairs) (void)hipFree(e->d_pairs);
   if (e->h_up) (void)hipHostFree(e->h_up);
   if (e->h_down) (void)hipHostFree(e->h_down);
-  e->d_pairs = nullptr; e->h_up = e->h_down = nullptr; e->d_work_counters = nullptr;
+  e->d_pairs = nullptr; e->h_up = e->h_down = nullptr; e->d_work_counters = nullptr; e->d_resume = nullptr;
   if (e->d_owner) (void)hipFree(e->d_owner);
   if (e->d_wide_ws) (void)hipFree(e->d_wide_ws);
   e->d_wide_ws = nullptr; e->wide_ws_capacity = 0;
@@ -164,7 +166,7 @@ bool use_wide_level(const phovo_engine *e, int n_pairs, int n_pixels)
 
 // Byte offsets of the per-launch pair data for n pairs (see phovo_engine::d_pairs); every section starts 8-byte aligned.
 struct PairLayout {
-  size_t src, tgt, states, reports, heads, total;
+  size_t src, tgt, states, reports, heads, resume, total;
 };
 PairLayout pair_layout(int n_pairs)
 {
@@ -175,7 +177,9 @@ PairLayout pair_layout(int n_pairs)
   l.states = l.tgt + sizeof(int) * n2;
   l.reports = l.states + sizeof(double) * 6 * (size_t)n_pairs;
   l.heads = l.reports + sizeof(phovo_pair_report) * (size_t)n_pairs;
-  l.total = l.heads + sizeof(int) * PHOVO_MAX_LEVELS * QUEUES_PER_LEVEL;
+  // two sets of heads per level: the sliding-window launch of a large level and its follow-up each drain their own queue
+  l.resume = l.heads + sizeof(int) * 2 * PHOVO_MAX_LEVELS * QUEUES_PER_LEVEL;
+  l.total = l.resume + sizeof(int) * n2;        // per-pair "continue in the exact kernel" marks of the sliding-window form
   return l;
 }
 
@@ -408,6 +412,8 @@ int phovo_engine_create(int device, phovo_engine **out)
     }
   }
   if (he == hipSuccess) he = gn_prepare_kernels();
+  if (he == hipSuccess) he = gn_prepare_slide_kernels();
+  e->slide_policy = std::getenv("PHOVO_GN_NO_SLIDE") ? -1 : 0;        // A/B switch for tools/
   if (he == hipSuccess) {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) e->cu_count = cus;
@@ -524,6 +530,14 @@ int phovo_engine_set_wide_policy(phovo_engine *e, int policy)
   if (!e) return fail(PHOVO_E_INVALID_ARGUMENT, "set_wide_policy: null");
   if (policy < -1 || policy > 1) return fail(PHOVO_E_INVALID_ARGUMENT, "set_wide_policy: policy must be -1, 0 or 1");
   e->wide_policy = policy;
+  return PHOVO_OK;
+}
+
+int phovo_engine_set_slide_policy(phovo_engine *e, int policy)
+{
+  if (!e) return fail(PHOVO_E_INVALID_ARGUMENT, "set_slide_policy: null");
+  if (policy < -1 || policy > 0) return fail(PHOVO_E_INVALID_ARGUMENT, "set_slide_policy: policy must be -1 or 0");
+  e->slide_policy = policy;
   return PHOVO_OK;
 }
 
@@ -842,6 +856,7 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
   e->d_states = reinterpret_cast<double *>(e->d_pairs + pl.states);
   e->d_reports = reinterpret_cast<phovo_pair_report *>(e->d_pairs + pl.reports);
   e->d_work_counters = reinterpret_cast<int *>(e->d_pairs + pl.heads);
+  e->d_resume = reinterpret_cast<int *>(e->d_pairs + pl.resume);
   std::memset(e->h_up, 0, pl.reports);
   std::memcpy(e->h_up + pl.src, source_frames, sizeof(int) * (size_t)n_pairs);
   std::memcpy(e->h_up + pl.tgt, target_frames, sizeof(int) * (size_t)n_pairs);
@@ -892,6 +907,14 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
       const bool few = n_pairs <= LATENCY_PAIRS && lv.plan_few_ok && lv.plan_few.owner_in_lds == lv.plan.owner_in_lds;
       const GNLaunchPlan &pl = few ? lv.plan_few : lv.plan;
       a.n_lds = pl.owner_in_lds ? 0 : pl.owner_lds_entries;
+      if (!pl.owner_in_lds && e->slide_policy >= 0) {
+        // Owner map too large for LDS: the sliding-window kernel first (owner ring in LDS); pairs whose warp leaves its
+        // window are marked in a.resume and continued, from the iteration they had reached, by the exact kernel right
+        // behind it -- which draws from its own queue and drops every pair that is not marked.
+        a.resume = e->d_resume;
+        PHOVO_HIP_CHECK(gn_launch_level_slide(a, e->ext.plane_storage, e->cu_count, e->stream));
+        a.work_counter = e->d_work_counters + (PHOVO_MAX_LEVELS + l) * QUEUES_PER_LEVEL;
+      }
       PHOVO_HIP_CHECK(gn_launch_level(a, pl, e->ext.plane_storage, e->cu_count, e->stream));
       if (!pl.owner_in_lds) e->owner_tagged = true;          // tagged entries stay behind (the kernel wipes per pair)
     }

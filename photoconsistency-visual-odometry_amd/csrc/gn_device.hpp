@@ -23,7 +23,7 @@ enum {
 };
 
 // Control words in LDS.
-enum { CTL_DONE = 0, CTL_FLAGS = 1, CTL_PAIR = 2, CTL_COUNT = 4 };
+enum { CTL_DONE = 0, CTL_FLAGS = 1, CTL_PAIR = 2, CTL_OOW = 3, CTL_COUNT = 4 };      // CTL_OOW: sliding-window kernel only
 
 __device__ __forceinline__ double uniform_f64(double v)
 {
@@ -241,6 +241,16 @@ __device__ __forceinline__ int draw_pair(int *heads, int n_queues, int n_pairs)
     q = (q + 1) & (n_queues - 1);
   }
   return n_pairs;
+}
+
+// Follow-up launch of a level (GNLevelArgs::resume != nullptr): only the pairs the sliding-window kernel marked are
+// taken; the others are drawn and dropped by the calling thread.
+__device__ __forceinline__ int draw_pair_resume(int *heads, int n_queues, int n_pairs, const int *resume)
+{
+  for (;;) {
+    const int p = draw_pair(heads, n_queues, n_pairs);
+    if (p >= n_pairs || resume == nullptr || __hip_atomic_load(&resume[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return p;
+  }
 }
 
 // v_writelane_b32: lane `lane` (wave-uniform) of `old` becomes `value` (wave-uniform); the other lanes keep theirs.

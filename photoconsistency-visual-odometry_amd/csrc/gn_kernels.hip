@@ -75,7 +75,9 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
   // the iteration loop and the barrier at the head of the work loop is one if-block (two adjacent `if (tid == 0)`
   // blocks, one either side of the back edge, were threaded together by the compiler into a loop that reached that
   // barrier with thread 0 parked: a hang).
-  if (tid == 0) s_ctl[CTL_PAIR] = draw_pair(A.work_counter, A.n_queues, A.n_pairs);
+  // (HUGE variant as the follow-up of the sliding-window kernel, A.resume != nullptr: only the pairs marked there)
+  if (tid == 0) s_ctl[CTL_PAIR] = OWNER_LDS ? draw_pair(A.work_counter, A.n_queues, A.n_pairs)
+                                            : draw_pair_resume(A.work_counter, A.n_queues, A.n_pairs, A.resume);
   for (;;) {
   // The ticket thread 0 has just stored must have LEFT its LDS queue before any wave is released: the compiler omits
   // the wait in front of this one barrier (it relies on LDS operations being ordered across waves), and on the GPU
@@ -142,6 +144,9 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
   const double cd0 = (double)c0, rd0 = (double)r0;
 
   int iteration = 0;
+  if constexpr (!OWNER_LDS) {       // continuing a pair the sliding-window kernel handed over: its completed iterations count
+    if (A.resume) iteration = __builtin_amdgcn_readfirstlane(A.reports[pair].iterations[A.level]);
+  }
   double last_gnorm = 0.0;
 #ifdef PHOVO_STAMPS
   unsigned long long st_sum[5] = {0, 0, 0, 0, 0};
@@ -502,6 +507,9 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
       A.reports[pair].iterations[A.level] = iteration;
       A.reports[pair].gradient_norm = last_gnorm;
       A.reports[pair].flags |= (uint32_t)s_ctl[CTL_FLAGS];
+      if constexpr (!OWNER_LDS) {
+        if (A.resume) A.reports[pair].flags |= PHOVO_PAIR_WINDOW_FALLBACK;
+      }
 #ifdef PHOVO_STAMPS
       // diagnostic build only: phase cycle sums of wave 0 go to the otherwise unused report slots 8..12
       for (int j = 0; j < 5; j++) A.reports[pair].iterations[8 + j] = (int)(st_sum[j] / (unsigned long long)iteration);
@@ -512,7 +520,11 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
       A.reports[pair].iterations[15] = (int)blockIdx.x;
 #endif
     }
-    s_ctl[CTL_PAIR] = draw_pair(A.work_counter, A.n_queues, A.n_pairs);
+    if constexpr (!OWNER_LDS) {
+      if (A.resume) A.resume[pair] = 0;         // taken care of (a later level may mark the pair again)
+    }
+    s_ctl[CTL_PAIR] = OWNER_LDS ? draw_pair(A.work_counter, A.n_queues, A.n_pairs)
+                                : draw_pair_resume(A.work_counter, A.n_queues, A.n_pairs, A.resume);
   }
   }   // next pair
 }

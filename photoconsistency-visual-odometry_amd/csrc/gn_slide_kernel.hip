@@ -1,0 +1,399 @@
+// Gauss-Newton level kernel for levels whose owner map does not fit LDS (more than ~39 k pixels: 320x240 of a
+// 1280x960 pyramid, 640x480 level 0): the SLIDING-WINDOW form.
+//
+// Same per-pixel arithmetic and the same reference semantics as gn_level_kernel (gn_kernels.hip; reference:
+// phovo/include/CPhotoconsistencyOdometryAnalytic.h:191-367, 376-392, 500-563), one workgroup per frame pair, whole
+// iteration loop of the level on the device.  What differs is where the scatter of the residuals (:358, last raster
+// writer wins) is resolved.  gn_level_kernel's HUGE variant keeps the owner map in HBM (tagged global atomics, 60 B per
+// pixel-iteration instead of 40, 0.51 of the roofline).  Here the map is a RING in LDS that slides down the image:
+//
+//   * the image is cut into bands of 4096 pixels (64 chunks of 64; each of the 16 waves owns 4 chunks of a band);
+//   * an iteration is a sequence of phases; in phase s every wave runs PASS 1 (warp, atomicMax into the ring) on its
+//     chunks of source band s and then PASS 2 (residual, Jacobian row, 27 sums) on its chunks of target band s - 4,
+//     one workgroup barrier per phase;
+//   * the ring holds 8 bands (32768 int32 = 128 KiB): while band s is warped, targets may fall into bands s-3 .. s+3;
+//     band s - 4 can no longer be written by anybody and is consumed (and reset to -1) by pass 2.  Rotations and
+//     translations of the sizes Gauss-Newton steps take move a pixel by a few rows; 3 bands are 38 rows at 320 px width.
+//   * a source pixel whose target falls OUTSIDE the window sets a flag.  The iteration is then void: the state is left
+//     as it was, the pair is marked in GNLevelArgs::resume and the engine's follow-up launch of gn_level_kernel (HBM
+//     owner map, exact for any motion) continues that pair from the same iteration.  Results are therefore exactly
+//     the reference's whatever the motion; only the speed depends on the window.
+//
+// A wave walks its chunks in the same order as in gn_level_kernel (wave, wave + 16, ...), so the 27 sums are
+// accumulated, reduced and solved in the same order.  Depth is read by both passes (four bands apart: the second read
+// is an L2 / Infinity Cache hit); no global atomics, no owner traffic in HBM.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include <type_traits>
+
+#include "gn_device.hpp"
+#include "phovo_internal.hpp"
+
+namespace phovo_hip {
+
+namespace {
+
+#ifndef PHOVO_SLIDE_T
+#define PHOVO_SLIDE_T 512
+#endif
+constexpr int SLIDE_T = PHOVO_SLIDE_T;                        // threads per workgroup (one workgroup per CU)
+constexpr int SLIDE_NW = SLIDE_T / WAVE;
+constexpr int SLIDE_B = 4;                                    // chunks per wave and band
+constexpr int SLIDE_BAND_CHUNKS = SLIDE_NW * SLIDE_B;         // 64
+constexpr int SLIDE_BAND_PX = SLIDE_BAND_CHUNKS * WAVE;       // 4096
+constexpr int SLIDE_RING_PX = 32768;                          // entries of the ring, a power of two (128 KiB)
+constexpr int SLIDE_RING_BANDS = SLIDE_RING_PX / SLIDE_BAND_PX;
+constexpr int SLIDE_M = (SLIDE_RING_BANDS - 2) / 2;           // targets of source band s lie in bands s-M .. s+M
+static_assert(2 * SLIDE_M + 2 <= SLIDE_RING_BANDS, "the band being consumed and the 2M+1 bands being written must be distinct ring slots");
+static_assert((SLIDE_RING_PX & (SLIDE_RING_PX - 1)) == 0, "ring index is a mask");
+static_assert((SLIDE_M + 2) * SLIDE_B <= 64, "in-bounds ballots of the chunks between pass 1 and pass 2 live in 64 register lanes");
+
+template <typename TI, typename TD>
+__global__ __launch_bounds__(SLIDE_T, SLIDE_T / 256) void gn_level_kernel_slide(const GNLevelArgs A)
+{
+  constexpr int T = SLIDE_T, NW = SLIDE_NW, B = SLIDE_B;
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  double *s_cst = reinterpret_cast<double *>(lds_raw);                 // [32]
+  double *s_state = s_cst + 32;                                        // [8]
+  double *s_red = s_state + 8;                                         // [NW][NRED]
+  int *s_ctl = reinterpret_cast<int *>(s_red + NW * NRED);             // [CTL_COUNT]
+  int *s_owner = s_ctl + CTL_COUNT;                                    // [SLIDE_RING_PX]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & (WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
+  const int n = A.n, W = A.w, H = A.h;
+  const int n_bands = (A.n_chunks + SLIDE_BAND_CHUNKS - 1) / SLIDE_BAND_CHUNKS;
+  // Work queue and loop shape exactly as in gn_level_kernel (one exit every wave reaches; the next ticket is drawn in the
+  // block that writes the finished pair back; explicit LDS wait in front of the barrier at the loop head).
+  if (tid == 0) s_ctl[CTL_PAIR] = draw_pair(A.work_counter, A.n_queues, A.n_pairs);
+  for (;;) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int pair = __builtin_amdgcn_readfirstlane(s_ctl[CTL_PAIR]);
+  if (pair >= A.n_pairs) break;
+
+  const unsigned char *src_frame = A.planes + (size_t)A.src[pair] * A.frame_bytes;
+  const unsigned char *tgt_frame = A.planes + (size_t)A.tgt[pair] * A.frame_bytes;
+  const __amdgpu_buffer_rsrc_t rI0 = plane_rsrc<TI>(src_frame + A.plane_off[PLANE_I], n);
+  const __amdgpu_buffer_rsrc_t rD0 = plane_rsrc<TD>(src_frame + A.plane_off[PLANE_D], n);
+  const __amdgpu_buffer_rsrc_t rI1 = plane_rsrc<TI>(tgt_frame + A.plane_off[PLANE_I], n);
+  const __amdgpu_buffer_rsrc_t rGX = plane_rsrc<TI>(tgt_frame + A.plane_off[PLANE_GX], n);
+  const __amdgpu_buffer_rsrc_t rGY = plane_rsrc<TI>(tgt_frame + A.plane_off[PLANE_GY], n);
+
+  // ---- pair prologue: empty ring, pose constants --------------------------------------------------------
+  for (int k = tid; k < SLIDE_RING_PX; k += T) s_owner[k] = -1;
+  if (wave == 0) {
+    double st[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) st[j] = A.states[(size_t)pair * 6 + j];
+    write_pose_constants(st[0], st[1], st[2], st[3], st[4], st[5], s_cst, lane);
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < 6; j++) s_state[j] = st[j];
+      s_ctl[CTL_DONE] = 0;
+      s_ctl[CTL_FLAGS] = 0;
+      s_ctl[CTL_OOW] = 0;
+    }
+  }
+  __syncthreads();
+
+  const double fx = A.fx, fy = A.fy, ox = A.ox, oy = A.oy, ifx = A.ifx, ify = A.ify;
+  const double min_d = A.min_depth, max_d = A.max_depth;
+  const double dW = (double)W, dH = (double)H;
+  const double huber_delta = A.huber_delta;
+  const bool huber_on = huber_delta > 0.0;
+
+  const int k0 = wave * WAVE + lane;
+  const int r0 = k0 / W, c0 = k0 - r0 * W;
+  const int step_r = (NW * WAVE) / W, step_c = (NW * WAVE) - step_r * W;
+  const RowColStep rc_step = make_rowcol_step(step_r, step_c, W);
+  const double cd0 = (double)c0, rd0 = (double)r0;
+
+  int iteration = 0;
+  double last_gnorm = 0.0;
+  bool handed_over = false;
+  while (true) {
+    // ---- constants of this iteration (uniform -> SGPRs) ---------------------------------------------------
+    const double cx = uniform_f64(s_cst[C_X]), cyy = uniform_f64(s_cst[C_Y]), cz = uniform_f64(s_cst[C_Z]);
+    const double r01 = uniform_f64(s_cst[C_R01]), r02 = uniform_f64(s_cst[C_R02]);
+    const double r11 = uniform_f64(s_cst[C_R11]), r12 = uniform_f64(s_cst[C_R12]);
+    const double t1 = uniform_f64(s_cst[C_T1]), t2 = uniform_f64(s_cst[C_T2]), t3 = uniform_f64(s_cst[C_T3]);
+    const double t14 = uniform_f64(s_cst[C_T14]), t15 = uniform_f64(s_cst[C_T15]);
+    const double t4 = uniform_f64(s_cst[C_T4]), t5 = uniform_f64(s_cst[C_T5]), t6 = uniform_f64(s_cst[C_T6]);
+    const double t8 = uniform_f64(s_cst[C_T8]), t11 = uniform_f64(s_cst[C_T11]);
+    const double t16 = uniform_f64(s_cst[C_T16]), t17 = uniform_f64(s_cst[C_T17]), t24 = uniform_f64(s_cst[C_T24]);
+    const double cosy = uniform_f64(s_cst[C_CY]), siny = uniform_f64(s_cst[C_SY]);
+    const double t7 = -t6, t9 = -t8, t21 = -t5;
+
+    double acc[NRED];
+#pragma unroll
+    for (int j = 0; j < NRED; j++) acc[j] = 0.0;
+
+    // Two cursors walk the wave's chunks (wave, wave + NW, ...): pass 1 leads, pass 2 follows (M + 1) bands behind.
+    int k1 = k0, j1 = 0;
+    double cd1 = cd0, rd1 = rd0;
+    int k2 = k0, j2 = 0;
+    double cd2 = cd0, rd2 = rd0;
+    // chunk j's "valid and landed in bounds" ballot lives in lane (j & 63) of two registers from pass 1 to pass 2
+    int inb_lo = 0, inb_hi = 0;
+    // software prefetch, one chunk ahead in each pass
+    double pz_next = plane_load<TD>(rD0, k1);
+    double pz_n = plane_load<TD>(rD0, k2), gx_n = plane_load<TI>(rGX, k2), gy_n = plane_load<TI>(rGY, k2),
+           i1_n = plane_load<TI>(rI1, k2);
+
+    // ---- pass 1 on one chunk: warp, bounds, window, atomicMax into the ring  (:279-303, 358) ---------------
+    auto pass1_chunk = [&](const int win_lo, const unsigned win_span) {
+      const double pz = pz_next;                                        // :279
+      pz_next = plane_load<TD>(rD0, k1 + NW * WAVE);                    // past the plane: 0
+      const double px = (cd1 - ox) * pz * ifx;                          // :282
+      const double py = (rd1 - oy) * pz * ify;                          // :283
+      const double X = fma(r02, pz, fma(r01, py, fma(t15, px, cx)));    // Rt*point3D  :291
+      const double Y = fma(r12, pz, fma(r11, py, fma(t14, px, cyy)));
+      const double Z = fma(t2, pz, fma(t1, py, fma(-t3, px, cz)));
+      const double iz = fast_rcp(Z);                                    // :294
+      const double tc = (X * fx) * iz + ox;                             // :295
+      const double tr = (Y * fy) * iz + oy;                             // :296
+      const double rr = round_half_up_from(tr), rc = round_half_up_from(tc);       // :297-298 (arguments > -0.5)
+      unsigned long long m =
+          __builtin_amdgcn_ballot_w64(k1 < n) & __builtin_amdgcn_ballot_w64(min_d < pz) &
+          __builtin_amdgcn_ballot_w64(pz < max_d) & __builtin_amdgcn_ballot_w64(tr > -0.5) &
+          __builtin_amdgcn_ballot_w64(rr < dH) & __builtin_amdgcn_ballot_w64(tc > -0.5) &
+          __builtin_amdgcn_ballot_w64(rc < dW);                         // :280, :302-303
+      const int t = (int)fma(rr, dW, rc);
+      // inside the window of this phase?  (unsigned compare: below win_lo wraps to a huge value)
+      const unsigned long long inside = __builtin_amdgcn_ballot_w64((unsigned)(t - win_lo) < win_span);
+      if (m & ~inside) {                                                // wave-uniform, rare: this iteration is void
+        if (lane == 0) s_ctl[CTL_OOW] = 1;
+        m &= inside;
+      }
+      if (__builtin_amdgcn_inverse_ballot_w64(m)) atomicMax(&s_owner[t & (SLIDE_RING_PX - 1)], k1);   // :358
+      inb_lo = writelane_b32(inb_lo, (int)(unsigned)m, j1 & 63);
+      inb_hi = writelane_b32(inb_hi, (int)(unsigned)(m >> 32), j1 & 63);
+      k1 += NW * WAVE;
+      j1++;
+      rowcol_advance(cd1, rd1, rc_step);
+    };
+
+    // ---- pass 2 on one chunk: residual, Jacobian row, accumulation  (:308-356, 538-540) -------------------
+    auto pass2_chunk = [&](auto huber_tag, const int o, const double pixel1) {
+      constexpr bool HUBER = decltype(huber_tag)::value;
+      const double pz = pz_n, gxi = gx_n, gyi = gy_n, pixel2 = i1_n;
+      {
+        const int kk = k2 + NW * WAVE;
+        pz_n = plane_load<TD>(rD0, kk);
+        gx_n = plane_load<TI>(rGX, kk);                                 // gradient at the SOURCE index  :346-347
+        gy_n = plane_load<TI>(rGY, kk);
+        i1_n = plane_load<TI>(rI1, kk);                                 // :309
+      }
+      const unsigned long long mbits =
+          ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(inb_hi, j2 & 63) << 32) |
+          (unsigned long long)(unsigned)__builtin_amdgcn_readlane(inb_lo, j2 & 63);
+      if (__builtin_amdgcn_inverse_ballot_w64(mbits)) {
+        const double res = (o >= 0) ? (pixel2 - pixel1) : 0.0;          // :358
+        const double px = (cd2 - ox) * pz * ifx;
+        const double py = (rd2 - oy) * pz * ify;
+        // factored Jacobian, derivation in gn_kernels.hip (pass 2)
+        const double Zr = py * t1 + pz * t2 - px * t3;
+        const double t25 = fast_rcp(cz + Zr);                           // :313
+        const double Au = pz * t4 + py * t5 + px * t11;                 // temp11 = temp15 + x: the reference's slip (:253), kept
+        const double Bv = py * t6 + pz * t9 + px * t14 + cyy;
+        const double Cm = -py * t16 - pz * t17 - px * t24;
+        const double Dm = py * t2 - pz * t1;
+        double J[6];
+        J[0] = (gxi * fx) * t25;                                        // :317
+        J[1] = (gyi * fy) * t25;                                        // :322
+        J[2] = -(J[0] * Au + J[1] * Bv) * t25;                          // :325-326
+        J[3] = J[0] * (cyy - Bv) + J[1] * (Au - px * cx);               // :329-330
+        J[4] = (J[0] * cosy + J[1] * siny) * Zr + Cm * J[2];            // :333-336
+        J[5] = J[0] * (py * t4 + pz * t21) + J[1] * (pz * t7 + py * t9) + Dm * J[2];     // :339-342
+        double Jw[6];
+#pragma unroll
+        for (int a = 0; a < 6; a++) Jw[a] = J[a];
+        if (HUBER) {                 // extension, not in the reference: IRLS weight of the Huber loss
+          const double ar = fabs(res);
+          const double wgt = ar <= huber_delta ? 1.0 : huber_delta / ar;
+#pragma unroll
+          for (int a = 0; a < 6; a++) Jw[a] = J[a] * wgt;
+        }
+        int q = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+#pragma unroll
+          for (int b = a; b < 6; b++) {
+            acc[q] = fma(Jw[a], J[b], acc[q]);                          // J^T (W) J  :540
+            q++;
+          }
+        }
+#pragma unroll
+        for (int a = 0; a < 6; a++) acc[21 + a] = fma(Jw[a], res, acc[21 + a]);   // J^T (W) r  :538
+      }
+      k2 += NW * WAVE;
+      j2++;
+      rowcol_advance(cd2, rd2, rc_step);
+    };
+
+    // ---- the phases of this iteration ---------------------------------------------------------------------
+    for (int s = 0; s < n_bands + SLIDE_M + 1; s++) {                   // wave-uniform bounds throughout
+      const int s2 = s - (SLIDE_M + 1);
+      // owners of this phase's pass-2 band: the ring slots are final (nobody writes band s2 any more), are read and
+      // reset here, and the gathers of the owning source intensities go out before pass 1 so that they arrive under it
+      int own[B];
+      double i0v[B];
+#pragma unroll
+      for (int b = 0; b < B; b++) { own[b] = -1; i0v[b] = 0.0; }
+      if (s2 >= 0) {
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+          const int kk = k2 + b * NW * WAVE;
+          if (kk < n) {
+            own[b] = s_owner[kk & (SLIDE_RING_PX - 1)];
+            s_owner[kk & (SLIDE_RING_PX - 1)] = -1;                     // ready for the band that reuses this slot
+          }
+        }
+#pragma unroll
+        for (int b = 0; b < B; b++) i0v[b] = plane_load<TI>(rI0, own[b]);      // :308 (owner -1: past the plane -> 0)
+      }
+      if (s < n_bands) {
+        const int win_lo = (s - SLIDE_M) * SLIDE_BAND_PX;
+        const unsigned win_span = (unsigned)((2 * SLIDE_M + 1) * SLIDE_BAND_PX);
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+          if (s * SLIDE_BAND_CHUNKS + b * NW + wave < A.n_chunks) pass1_chunk(win_lo, win_span);
+        }
+      }
+      if (s2 >= 0) {
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+          if (s2 * SLIDE_BAND_CHUNKS + b * NW + wave < A.n_chunks) {
+            if (huber_on) pass2_chunk(std::true_type{}, own[b], i0v[b]);
+            else pass2_chunk(std::false_type{}, own[b], i0v[b]);
+          }
+        }
+      }
+      __syncthreads();
+    }
+
+    // ---- wave-level transposed butterfly, cross-wave sum, solve, update, terminate (as gn_level_kernel) ---
+    reduce_stage_swap<32, false>(acc);
+    reduce_stage_swap<16, true>(acc);
+    reduce_stage<8, 4>(acc, lane, 8);
+    reduce_stage<4, 4>(acc, lane, 4);
+    reduce_stage<2, 4>(acc, lane, 2);
+    {
+      const double total = acc[0] + __shfl_xor(acc[0], 1, WAVE);
+      const int idx = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 +
+                      ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+      if ((lane & 1) == 0) s_red[wave * NRED + idx] = total;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      double v = 0.0;
+      {
+        const int j = lane & (NRED - 1);
+        const int w0 = (lane >> 5) * (NW / 2);
+#pragma unroll
+        for (int w2 = 0; w2 < NW / 2; w2++) v += s_red[(w0 + w2) * NRED + j];
+        v += __shfl_xor(v, 32, WAVE);
+      }
+      double h[21], g[6];
+#pragma unroll
+      for (int q = 0; q < 21; q++) h[q] = __shfl(v, q, WAVE);
+#pragma unroll
+      for (int i = 0; i < 6; i++) g[i] = __shfl(v, 21 + i, WAVE);
+      const bool void_iteration = s_ctl[CTL_OOW] != 0;                  // wave-uniform
+      double step[6];
+      solve6_ldlt(h, g, step);
+      double st[6];
+      bool finite = true;
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        st[i] = s_state[i] - A.lambda * step[i];                        // :539
+        finite = finite && (fabs(st[i]) <= 1.79769313486231570815e308);
+      }
+      double gn2 = 0.0;
+#pragma unroll
+      for (int i = 0; i < 6; i++) gn2 += g[i] * g[i];
+      const double gnorm = sqrt(gn2);                                   // :380
+      const int it = iteration + 1;                                     // :547
+      bool done = false;
+      if (it >= A.max_iter) done = true;                                // :383
+      else if (gnorm < A.min_grad_norm) done = true;                    // :388
+      if (!finite) done = true;
+      if (void_iteration) {
+        // a source pixel left the window: nothing of this iteration counts; the pair goes to the exact kernel
+        if (lane == 0) { s_ctl[CTL_DONE] = 2; }
+      } else {
+        if (!done) write_pose_constants(st[0], st[1], st[2], st[3], st[4], st[5], s_cst, lane);
+        if (lane == 0) {
+#pragma unroll
+          for (int i = 0; i < 6; i++) s_state[i] = st[i];
+          s_ctl[CTL_DONE] = done ? 1 : 0;
+          if (!finite) s_ctl[CTL_FLAGS] |= (int)PHOVO_PAIR_NONFINITE;
+        }
+        last_gnorm = gnorm;
+      }
+    }
+    __syncthreads();
+    const int done_word = s_ctl[CTL_DONE];
+    if (done_word == 2) { handed_over = true; break; }
+    iteration++;
+    if (done_word) break;
+  }
+
+  // ---- epilogue: state and report back to HBM -------------------------------------------------------------
+  if (tid == 0) {
+#pragma unroll
+    for (int j = 0; j < 6; j++) A.states[(size_t)pair * 6 + j] = s_state[j];
+    if (A.reports) {
+      A.reports[pair].iterations[A.level] = iteration;                  // completed iterations (the exact kernel resumes here)
+      A.reports[pair].gradient_norm = last_gnorm;
+      A.reports[pair].flags |= (uint32_t)s_ctl[CTL_FLAGS];
+    }
+    if (handed_over) A.resume[pair] = 1;
+    s_ctl[CTL_PAIR] = draw_pair(A.work_counter, A.n_queues, A.n_pairs);
+  }
+  }   // next pair
+}
+
+}  // namespace
+
+size_t gn_slide_lds_bytes()
+{
+  return sizeof(double) * (32 + 8 + (size_t)SLIDE_NW * NRED) + sizeof(int) * (CTL_COUNT + (size_t)SLIDE_RING_PX);
+}
+
+int gn_slide_window_pixels() { return SLIDE_M * SLIDE_BAND_PX; }
+
+hipError_t gn_prepare_slide_kernels()
+{
+  hipError_t e;
+#define PHOVO_PREP_SLIDE(TI, TD)                                                                                   \
+  e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gn_level_kernel_slide<TI, TD>),                          \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)gn_slide_lds_bytes());                  \
+  if (e != hipSuccess) return e;
+  PHOVO_PREP_SLIDE(double, double)
+  PHOVO_PREP_SLIDE(float, float)
+  PHOVO_PREP_SLIDE(__half, float)
+#undef PHOVO_PREP_SLIDE
+  return hipSuccess;
+}
+
+hipError_t gn_launch_level_slide(const GNLevelArgs &a, int storage, int cu_count, hipStream_t stream)
+{
+  if (a.n_pairs <= 0) return hipSuccess;
+  if (!a.resume) return hipErrorInvalidValue;
+  const int n_blocks = a.n_pairs < cu_count ? a.n_pairs : cu_count;     // persistent grid, one workgroup per CU
+  const dim3 grid((unsigned)n_blocks), block((unsigned)SLIDE_T);
+  const size_t lds = gn_slide_lds_bytes();
+  switch (storage) {
+    case PHOVO_STORAGE_F64: hipLaunchKernelGGL((gn_level_kernel_slide<double, double>), grid, block, lds, stream, a); break;
+    case PHOVO_STORAGE_F32: hipLaunchKernelGGL((gn_level_kernel_slide<float, float>), grid, block, lds, stream, a); break;
+    case PHOVO_STORAGE_F16: hipLaunchKernelGGL((gn_level_kernel_slide<__half, float>), grid, block, lds, stream, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace phovo_hip

@@ -37,6 +37,9 @@ struct GNLevelArgs {
   int *work_counter;        // [QUEUES_PER_LEVEL] heads, zeroed before the launch: workgroups draw pair indices from them
   int n_queues;             // 1: one queue for the whole grid; 8: one per XCD over a contiguous eighth of the pairs (+ stealing)
   int n_lds;                // owner map in HBM only: its first n_lds entries (a multiple of 64) live in LDS instead
+  int *resume;              // [pairs] or nullptr.  Sliding-window kernel (gn_slide_kernel.hip): sets resume[p] = 1 for a pair
+                            // whose warp left the window; the follow-up launch of gn_level_kernel (owner map in HBM) takes
+                            // only those pairs and continues each at reports[p].iterations[level]
 };
 
 constexpr int QUEUES_PER_LEVEL = 8;      // one per XCD
@@ -68,6 +71,12 @@ size_t gn_wide_workspace_bytes(int n, int n_pairs);
 hipError_t gn_run_level_wide(const GNLevelArgs &args, int n_pairs, void *workspace, int *h_done_scratch,
                              hipStream_t stream);
 hipError_t gn_prepare_kernels();   // raises the dynamic-LDS limit of every instantiation
+// Sliding-window form for levels whose owner map exceeds LDS (gn_slide_kernel.hip): owner ring in LDS; pairs whose
+// motion leaves the window are marked in args.resume for a follow-up gn_launch_level with the same args.
+hipError_t gn_prepare_slide_kernels();
+hipError_t gn_launch_level_slide(const GNLevelArgs &args, int storage, int cu_count, hipStream_t stream);
+size_t gn_slide_lds_bytes();
+int gn_slide_window_pixels();      // a target may lie this many pixels (linear index) before / after its source's band
 
 // Pyramid producers (SetSourceFrame / SetTargetFrame, ...Analytic.h:466-491), batched over `frames`
 // consecutive frames: frame f reads src + f*src_frame_stride and writes dst + f*dst_frame_stride (elements).

@@ -15,6 +15,7 @@ MAX_LEVELS = 16
 
 ROLE_SOURCE, ROLE_TARGET, ROLE_BOTH = 1, 2, 3
 PAIR_NONFINITE = 1
+PAIR_WINDOW_FALLBACK = 2
 
 
 class PhovoError(RuntimeError):
@@ -102,6 +103,7 @@ SYMBOLS = {
     "phovo_engine_set_depth_range": (C.c_int, [_vp, C.c_double, C.c_double]),
     "phovo_engine_set_build_all_levels": (C.c_int, [_vp, C.c_int]),
     "phovo_engine_set_wide_policy": (C.c_int, [_vp, C.c_int]),
+    "phovo_engine_set_slide_policy": (C.c_int, [_vp, C.c_int]),
     "phovo_engine_level_uses_wide": (C.c_int, [_vp, C.c_int, C.c_int]),
     "phovo_engine_reserve_frames": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),
     "phovo_engine_level_size": (C.c_int, [_vp, C.c_int, _ip, _ip]),

@@ -206,6 +206,10 @@ class AlignmentEngine:
         """0 automatic, 1 wide form wherever possible, -1 persistent form only."""
         check(self._lib.phovo_engine_set_wide_policy(self._h, int(policy)), "phovo_engine_set_wide_policy")
 
+    def set_slide_policy(self, policy):
+        """0 automatic (sliding-window kernel on levels whose owner map exceeds LDS), -1 exact kernel only."""
+        check(self._lib.phovo_engine_set_slide_policy(self._h, int(policy)), "phovo_engine_set_slide_policy")
+
     def level_uses_wide(self, level, n_pairs):
         return bool(self._lib.phovo_engine_level_uses_wide(self._h, int(level), int(n_pairs)))
 

@@ -292,6 +292,7 @@ def test_hbm_owner_map_tags_survive_wraparound_and_form_changes():
     short_n, short_o = _cfgs(1, [6], [0.0])
     es6, eits6 = oracle.align_frames(short_o, p["K"], p["gray0"], p["depth0"], p["gray1"])
     with odometry.AlignmentEngine() as eng:
+        eng.set_slide_policy(-1)                 # the exact kernel (owner map in HBM) itself, not the sliding-window form
         eng.set_intrinsic_matrix(p["K"])
         eng.set_config(short_n)
         eng.reserve_frames(2, w, h)
@@ -312,6 +313,96 @@ def test_hbm_owner_map_tags_survive_wraparound_and_form_changes():
     assert list(rd[0].iterations[:1]) == eits == [1040]
     assert se3.state_distance(d[0], es) < POSE_TOL
     assert all(np.array_equal(d[0], d[i]) for i in range(40))
+
+
+def _render_pair_with_motion(seed, w, h, motion, holes=0.02):
+    scene = synthetic.Scene(seed)
+    K = synthetic.intrinsics(w, h)
+    g0, d0 = synthetic.render(scene, np.eye(4), w, h, K, holes, hole_seed=2 * seed)
+    g1, d1 = synthetic.render(scene, se3.eigen_pose(motion), w, h, K, holes, hole_seed=2 * seed + 1)
+    return dict(gray0=g0, depth0=d0, gray1=g1, depth1=d1, K=K, motion=np.array(motion))
+
+
+@pytest.mark.parametrize("size,iters", [((320, 240), 9), ((640, 480), 4), ((330, 250), 5)])
+def test_sliding_window_kernel_matches_exact_kernel_and_oracle(size, iters):
+    """Levels whose owner map exceeds LDS: the sliding-window kernel (owner ring in LDS, gn_slide_kernel.hip) against the
+    exact kernel (owner map in HBM) and the oracle.  48 pairs per launch (persistent form), three problems of different
+    motion, every pair inside the window: no pair may be flagged as a fallback."""
+    w, h = size
+    probs = [synthetic.make_pair(80 + i, w, h, holes=0.02 * i, trans=0.01 * (i + 1), rot=0.004 * (i + 1)) for i in range(3)]
+    ncfg, ocfg = _cfgs(1, [iters], [0.0])
+    expect = [oracle.align_frames(ocfg, p["K"], p["gray0"], p["depth0"], p["gray1"]) for p in probs]
+    with odometry.AlignmentEngine() as eng:
+        eng.set_config(ncfg)
+        eng.set_intrinsic_matrix(probs[0]["K"])
+        eng.reserve_frames(6, w, h)
+        assert not eng.level_launch_info(0)["owner_in_lds"]
+        for i, p in enumerate(probs):
+            eng.upload_frame(2 * i, p["gray0"], p["depth0"], roles=native.ROLE_SOURCE)
+            eng.upload_frame(2 * i + 1, p["gray1"], None, roles=native.ROLE_TARGET)
+        src = [2 * (k % 3) for k in range(48)]
+        tgt = [2 * (k % 3) + 1 for k in range(48)]
+        assert not eng.level_uses_wide(0, 48)
+        slide, rs = eng.align_pairs(src, tgt, want_reports=True)
+        slide2 = eng.align_pairs(src, tgt)                                # ring left clean, deterministic
+        eng.set_slide_policy(-1)
+        exact, re_ = eng.align_pairs(src, tgt, want_reports=True)
+    assert np.array_equal(slide, slide2)
+    for k in range(48):
+        es, eits = expect[k % 3]
+        assert list(rs[k].iterations[:1]) == eits == list(re_[k].iterations[:1])
+        assert rs[k].flags == 0 and re_[k].flags == 0                     # nobody left the window
+        assert se3.state_distance(slide[k], es) < POSE_TOL and se3.state_distance(exact[k], es) < POSE_TOL
+        assert np.array_equal(slide[k], slide[k % 3]) and np.array_equal(exact[k], exact[k % 3])
+        assert abs(rs[k].gradient_norm - re_[k].gradient_norm) <= 1e-9 * max(1.0, re_[k].gradient_norm)
+
+
+def test_sliding_window_hands_large_motions_to_the_exact_kernel():
+    """An in-plane rotation of 0.3 rad moves the pixels at the image border by ~48 rows at 320x240: more than the ring of
+    the sliding-window kernel covers (3 bands of 4096 pixels = 38 rows).  Such pairs must be completed by the exact
+    kernel, from the iteration at which they left the window, with the reference's result: (a) out of the window from
+    the first iteration, (b) drifting out of it after a few iterations, (c) a well-behaved pair in the same launch
+    that must not be touched.  48 pairs, mixed."""
+    w, h = 320, 240
+    big = _render_pair_with_motion(91, w, h, [0.01, -0.005, 0.004, 0.30, 0.002, -0.003])
+    small = synthetic.make_pair(92, w, h, holes=0.02, trans=0.01, rot=0.004)
+    ncfg, ocfg = _cfgs(1, [8], [0.0])
+    init_a = big["motion"] + np.array([0.004, 0.002, -0.003, 0.004, -0.002, 0.001])      # near the truth: yaw 0.3 at once
+    init_b = np.array([0.0, 0.0, 0.0, 0.17, 0.0, 0.0])                                    # inside at first, converging outwards
+    cases = [(big, init_a), (big, init_b), (small, np.zeros(6))]
+    expect = []
+    for p, init in cases:
+        i0p, d0p = oracle.build_source_pyramids(p["gray0"], p["depth0"], ocfg)
+        i1p, gxp, gyp = oracle.build_target_pyramids(p["gray1"], ocfg)
+        expect.append(oracle.optimize(ocfg, p["K"], i0p, d0p, i1p, gxp, gyp, init_state=init))
+    with odometry.AlignmentEngine() as eng:
+        eng.set_config(ncfg)
+        eng.set_intrinsic_matrix(big["K"])
+        eng.reserve_frames(4, w, h)
+        for i, p in enumerate((big, small)):
+            eng.upload_frame(2 * i, p["gray0"], p["depth0"], roles=native.ROLE_SOURCE)
+            eng.upload_frame(2 * i + 1, p["gray1"], None, roles=native.ROLE_TARGET)
+        which = [k % 3 for k in range(48)]
+        src = [0 if c < 2 else 2 for c in which]
+        tgt = [1 if c < 2 else 3 for c in which]
+        init = np.stack([cases[c][1] for c in which])
+        s, reps = eng.align_pairs(src, tgt, init_states=init, want_reports=True)
+        eng.set_slide_policy(-1)
+        s_exact, reps_exact = eng.align_pairs(src, tgt, init_states=init, want_reports=True)
+    for k, c in enumerate(which):
+        es, eits = expect[c]
+        assert list(reps[k].iterations[:1]) == eits == [8], (k, c, list(reps[k].iterations[:1]))
+        assert se3.state_distance(s[k], es) < POSE_TOL, (k, c, se3.state_distance(s[k], es))
+        assert se3.state_distance(s_exact[k], es) < POSE_TOL
+        if c < 2:
+            assert reps[k].flags == native.PAIR_WINDOW_FALLBACK, (k, c, reps[k].flags)
+            assert np.array_equal(s[k], s[c])
+        else:
+            assert reps[k].flags == 0
+        assert reps_exact[k].flags == 0
+    # case (a) left the window in its first iteration: the exact kernel did all of it, bit for bit what it does alone
+    assert np.array_equal(s[0], s_exact[0])
+    assert abs(expect[1][0][3] - 0.30) < 0.05            # case (b) did converge towards the large rotation
 
 
 # ---------------------------------------------------------------------------------------------

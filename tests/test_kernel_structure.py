@@ -25,13 +25,14 @@ CSRC = os.path.join(ROOT, "photoconsistency-visual-odometry_amd", "csrc")
 @pytest.fixture(scope="module")
 def kernels():
     subprocess.run(["make", "-s", "-C", CSRC, "isa"], check=True, capture_output=True)
-    lines = open(os.path.join(CSRC, "build", "gn_kernels.s")).read().split("\n")
-    starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN9phovo_hip.*gn_level_kernel.*:", l)]
-    assert len(starts) >= 15, "expected every storage x variant instantiation of the level kernels"
     out = {}
-    for a in starts:
-        b = next(i for i in range(a, len(lines)) if "s_endpgm" in lines[i])
-        out[lines[a].split(":")[0]] = lines[a:b + 1]
+    for name, least in (("gn_kernels.s", 15), ("gn_slide_kernel.s", 3)):
+        lines = open(os.path.join(CSRC, "build", name)).read().split("\n")
+        starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN9phovo_hip.*gn_level_kernel.*:", l)]
+        assert len(starts) >= least, f"{name}: expected every storage x variant instantiation of the level kernels"
+        for a in starts:
+            b = next(i for i in range(a, len(lines)) if "s_endpgm" in lines[i])
+            out[lines[a].split(":")[0]] = lines[a:b + 1]
     return out
 
 
@@ -47,6 +48,12 @@ def test_work_loop_head_is_the_barrier(kernels):
     branches or narrows the exec mask may come first (register spill moves and waits may)."""
     for name, body in kernels.items():
         heads = [i for i, l in enumerate(body) if "This Loop Header: Depth=1" in l]
+        # The variant with the owner map in HBM (...Lb0ELb0ELb0E...) can run as the follow-up of the sliding-window kernel
+        # and then draws until it finds a pair marked for it: thread 0's first draw is a small loop of its own IN FRONT
+        # of the work loop (no barrier inside: only thread 0 is in it, and the queue heads only grow, so it ends).
+        if len(heads) == 2 and "ELb0ELb0ELb0E" in name:
+            assert not any(l.strip() == "s_barrier" for l in body[heads[0]:heads[1]]), f"{name}: barrier inside the draw loop"
+            heads = heads[1:]
         assert len(heads) == 1, f"{name}: expected exactly one outermost loop (the work queue), found {len(heads)}"
         i, waited = heads[0] + 1, False
         while True:
@@ -68,7 +75,7 @@ def test_work_loop_head_is_the_barrier(kernels):
 def test_every_barrier_waits_for_lds_first():
     subprocess.run(["make", "-s", "-C", CSRC, "isa"], check=True, capture_output=True)
     total = 0
-    for name in ("gn_kernels", "gn_wide_kernels", "pyramid_kernels", "warp_kernels"):
+    for name in ("gn_kernels", "gn_slide_kernel", "gn_wide_kernels", "pyramid_kernels", "warp_kernels"):
         lines = open(os.path.join(CSRC, "build", name + ".s")).read().split("\n")
         for i, l in enumerate(lines):
             if l.strip() != "s_barrier":
