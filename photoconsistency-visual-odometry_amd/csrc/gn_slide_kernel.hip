@@ -7,24 +7,27 @@
 // writer wins) is resolved.  gn_level_kernel's HUGE variant keeps the owner map in HBM (tagged global atomics, 60 B per
 // pixel-iteration instead of 40, 0.51 of the roofline).  Here the map is a RING in LDS that slides down the image:
 //
-//   * the image is cut into bands of 4096 pixels (64 chunks of 64; each of the 16 waves owns 4 chunks of a band);
+//   * the image is cut into bands of 2048 pixels (32 chunks of 64; each of the 8 waves owns 4 chunks of a band);
 //   * an iteration is a sequence of phases; in phase s every wave runs PASS 1 (warp, atomicMax into the ring) on its
-//     chunks of source band s and then PASS 2 (residual, Jacobian row, 27 sums) on its chunks of target band s - 4,
+//     chunks of source band s and then PASS 2 (residual, Jacobian row, 27 sums) on its chunks of target band s - 8,
 //     one workgroup barrier per phase;
-//   * the ring holds 8 bands (32768 int32 = 128 KiB): while band s is warped, targets may fall into bands s-3 .. s+3;
-//     band s - 4 can no longer be written by anybody and is consumed (and reset to -1) by pass 2.  Rotations and
-//     translations of the sizes Gauss-Newton steps take move a pixel by a few rows; 3 bands are 38 rows at 320 px width.
+//   * the ring holds 16 bands (32768 int32 = 128 KiB): while band s is warped, targets may fall into bands s-6 .. s+7;
+//     band s - 7 is final when the phase begins -- its owners are read then, and the source intensities they point at
+//     are gathered, a whole phase before pass 2 needs them -- and band s - 8 is consumed by pass 2.  Rotations and
+//     translations of the sizes Gauss-Newton steps take move a pixel by a few rows; 6 bands are 38 rows at 320 px width.
 //   * a source pixel whose target falls OUTSIDE the window sets a flag.  The iteration is then void: the state is left
 //     as it was, the pair is marked in GNLevelArgs::resume and the engine's follow-up launch of gn_level_kernel (HBM
 //     owner map, exact for any motion) continues that pair from the same iteration.  Results are therefore exactly
 //     the reference's whatever the motion; only the speed depends on the window.
 //
-// A wave walks its chunks in the same order as in gn_level_kernel (wave, wave + 16, ...), so the 27 sums are
-// accumulated, reduced and solved in the same order.  Depth is read by both passes (four bands apart: the second read
-// is an L2 / Infinity Cache hit); no global atomics, no owner traffic in HBM.
+// A wave walks its chunks in the same order as gn_level_kernel would with 8 waves (wave, wave + 8, ...).  Depth is read by
+// both passes (eight bands apart: the second read is an L2 / Infinity Cache hit); no global atomics, no owner traffic in
+// HBM.  512 threads = 2 waves per SIMD and 256 registers: the two passes interleaved need them (27 sums + both passes'
+// operands a phase ahead), see the notes in the kernel.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "gn_device.hpp"
@@ -34,25 +37,28 @@ namespace phovo_hip {
 
 namespace {
 
-#ifndef PHOVO_SLIDE_T
-#define PHOVO_SLIDE_T 512
-#endif
-constexpr int SLIDE_T = PHOVO_SLIDE_T;                        // threads per workgroup (one workgroup per CU)
-constexpr int SLIDE_NW = SLIDE_T / WAVE;
-constexpr int SLIDE_B = 4;                                    // chunks per wave and band
-constexpr int SLIDE_BAND_CHUNKS = SLIDE_NW * SLIDE_B;         // 64
-constexpr int SLIDE_BAND_PX = SLIDE_BAND_CHUNKS * WAVE;       // 4096
 constexpr int SLIDE_RING_PX = 32768;                          // entries of the ring, a power of two (128 KiB)
-constexpr int SLIDE_RING_BANDS = SLIDE_RING_PX / SLIDE_BAND_PX;
-constexpr int SLIDE_M = (SLIDE_RING_BANDS - 2) / 2;           // targets of source band s lie in bands s-M .. s+M
-static_assert(2 * SLIDE_M + 2 <= SLIDE_RING_BANDS, "the band being consumed and the 2M+1 bands being written must be distinct ring slots");
 static_assert((SLIDE_RING_PX & (SLIDE_RING_PX - 1)) == 0, "ring index is a mask");
-static_assert((SLIDE_M + 2) * SLIDE_B <= 64, "in-bounds ballots of the chunks between pass 1 and pass 2 live in 64 register lanes");
 
-template <typename TI, typename TD>
-__global__ __launch_bounds__(SLIDE_T, SLIDE_T / 256) void gn_level_kernel_slide(const GNLevelArgs A)
+// Geometry of one instantiation: T threads, B chunks per wave and band.
+template <int T_, int B_>
+struct SlideGeom {
+  static constexpr int T = T_, B = B_, NW = T_ / WAVE;
+  static constexpr int BAND_CHUNKS = NW * B_;
+  static constexpr int BAND_PX = BAND_CHUNKS * WAVE;
+  static constexpr int RING_BANDS = SLIDE_RING_PX / BAND_PX;
+  // Source band s may write target bands s-M+1 .. s+M; band s-M is final when phase s begins (its owners are read
+  // then, a phase ahead of their use), band s-M-1 is consumed by pass 2 during phase s.
+  static constexpr int M = (RING_BANDS - 1) / 2;
+  static_assert(2 * M + 1 <= RING_BANDS, "the band being read and the 2M bands being written must be distinct ring slots");
+  static_assert((M + 2) * B_ <= 64, "in-bounds ballots of the chunks between pass 1 and pass 2 live in 64 register lanes");
+};
+
+template <int T, int B, typename TI, typename TD>
+__global__ __launch_bounds__(T, T / 256) void gn_level_kernel_slide(const GNLevelArgs A)
 {
-  constexpr int T = SLIDE_T, NW = SLIDE_NW, B = SLIDE_B;
+  using G = SlideGeom<T, B>;
+  constexpr int NW = G::NW, SLIDE_M = G::M, SLIDE_BAND_CHUNKS = G::BAND_CHUNKS, SLIDE_BAND_PX = G::BAND_PX;
   extern __shared__ __align__(16) unsigned char lds_raw[];
   double *s_cst = reinterpret_cast<double *>(lds_raw);                 // [32]
   double *s_state = s_cst + 32;                                        // [8]
@@ -110,17 +116,30 @@ __global__ __launch_bounds__(SLIDE_T, SLIDE_T / 256) void gn_level_kernel_slide(
   const int step_r = (NW * WAVE) / W, step_c = (NW * WAVE) - step_r * W;
   const RowColStep rc_step = make_rowcol_step(step_r, step_c, W);
   const double cd0 = (double)c0, rd0 = (double)r0;
+  // (row, column) of the pixel (M + 1) bands in front of k0, rows counted downwards from 0 into the negative: where pass 2's
+  // cursor starts; rowcol_advance carries it into the image
+  const int kb = k0 - (SLIDE_M + 1) * SLIDE_BAND_PX;
+  const int rb = -((-kb + W - 1) / W), cb = kb - rb * W;             // floor division for kb < 0
+  const double cd2_0 = (double)cb, rd2_0 = (double)rb;
 
   int iteration = 0;
   double last_gnorm = 0.0;
   bool handed_over = false;
   while (true) {
-    // ---- constants of this iteration (uniform -> SGPRs) ---------------------------------------------------
-    const double cx = uniform_f64(s_cst[C_X]), cyy = uniform_f64(s_cst[C_Y]), cz = uniform_f64(s_cst[C_Z]);
-    const double r01 = uniform_f64(s_cst[C_R01]), r02 = uniform_f64(s_cst[C_R02]);
-    const double r11 = uniform_f64(s_cst[C_R11]), r12 = uniform_f64(s_cst[C_R12]);
-    const double t1 = uniform_f64(s_cst[C_T1]), t2 = uniform_f64(s_cst[C_T2]), t3 = uniform_f64(s_cst[C_T3]);
-    const double t14 = uniform_f64(s_cst[C_T14]), t15 = uniform_f64(s_cst[C_T15]);
+    // ---- constants of this iteration ----------------------------------------------------------------------
+    // Pass 1 and pass 2 run interleaved here, so all 22 pose constants and the 10 intrinsics are live at once.  All in
+    // SGPRs (gn_level_kernel keeps each pass's own set there) they do not fit next to the descriptors and the loop state:
+    // they were spilled to register lanes and came back one v_readlane at a time, and every instruction with two of
+    // them as operands needed a copy first (one constant-bus read per instruction) -- 382 vector instructions per pair
+    // of chunks instead of 174.  So the twelve that meet another constant inside one instruction (the translation, the
+    // rotation entries of pass 1, temp1..3, temp14/15) live in vector registers -- with 2 waves per SIMD there are 256 --
+    // and the other twenty stay scalar.
+    auto vreg = [](double v) { asm volatile("" : "+v"(v)); return v; };
+    const double cx = vreg(s_cst[C_X]), cyy = vreg(s_cst[C_Y]), cz = vreg(s_cst[C_Z]);
+    const double r01 = vreg(s_cst[C_R01]), r02 = vreg(s_cst[C_R02]);
+    const double r11 = vreg(s_cst[C_R11]), r12 = vreg(s_cst[C_R12]);
+    const double t1 = vreg(s_cst[C_T1]), t2 = vreg(s_cst[C_T2]), t3 = vreg(s_cst[C_T3]);
+    const double t14 = vreg(s_cst[C_T14]), t15 = vreg(s_cst[C_T15]);
     const double t4 = uniform_f64(s_cst[C_T4]), t5 = uniform_f64(s_cst[C_T5]), t6 = uniform_f64(s_cst[C_T6]);
     const double t8 = uniform_f64(s_cst[C_T8]), t11 = uniform_f64(s_cst[C_T11]);
     const double t16 = uniform_f64(s_cst[C_T16]), t17 = uniform_f64(s_cst[C_T17]), t24 = uniform_f64(s_cst[C_T24]);
@@ -131,22 +150,36 @@ __global__ __launch_bounds__(SLIDE_T, SLIDE_T / 256) void gn_level_kernel_slide(
 #pragma unroll
     for (int j = 0; j < NRED; j++) acc[j] = 0.0;
 
-    // Two cursors walk the wave's chunks (wave, wave + NW, ...): pass 1 leads, pass 2 follows (M + 1) bands behind.
+    // Two cursors walk the wave's chunks (wave, wave + NW, ...): pass 1 leads, pass 2 follows (M + 1) bands behind and the
+    // owner reads M bands behind.  EVERY phase runs both passes on B chunks each, with no branch around a chunk: in
+    // the first M + 1 phases pass 2 walks "virtual" chunks in front of the image (negative pixel indices) and in the last
+    // M + 1 pass 1 walks past its end.  Such chunks load zeros (a buffer load outside its descriptor returns 0), ballot
+    // to an empty mask and do nothing.  A branch around a chunk body would cost far more than those idle chunks: the
+    // loads a chunk issues for the NEXT phase land in registers that are live around the loop, and at the join behind a
+    // conditional chunk the compiler parks each of them in a temporary, waits for it (s_waitcnt vmcnt(0)) and copies
+    // it -- which serialises every chunk behind its own prefetch (measured: 8.0 ms per launch either way, prefetch or not).
     int k1 = k0, j1 = 0;
     double cd1 = cd0, rd1 = rd0;
-    int k2 = k0, j2 = 0;
-    double cd2 = cd0, rd2 = rd0;
+    int k2 = k0 - (SLIDE_M + 1) * SLIDE_BAND_PX, j2 = -(SLIDE_M + 1) * B;
+    double cd2 = cd2_0, rd2 = rd2_0;
     // chunk j's "valid and landed in bounds" ballot lives in lane (j & 63) of two registers from pass 1 to pass 2
     int inb_lo = 0, inb_hi = 0;
-    // software prefetch, one chunk ahead in each pass
-    double pz_next = plane_load<TD>(rD0, k1);
-    double pz_n = plane_load<TD>(rD0, k2), gx_n = plane_load<TI>(rGX, k2), gy_n = plane_load<TI>(rGY, k2),
-           i1_n = plane_load<TI>(rI1, k2);
+    // Software prefetch, B chunks (one whole phase) ahead in each pass: chunk b of a phase takes its operands from slot b
+    // and refills the slot with chunk b of the NEXT phase.  Every wave then has 4 + 16 plane loads and 4 gathers in
+    // flight at all times (~12 KB; 8 waves per CU): the level is streamed from HBM, little of it stays in the Infinity
+    // Cache between iterations (2048 pairs x 3 MB), and one chunk ahead left the waves parked on s_waitcnt half the time.
+    double pzb[B], pz_s[B], gx_s[B], gy_s[B], i1_s[B];
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+      pzb[b] = plane_load<TD>(rD0, k0 + b * NW * WAVE);
+      pz_s[b] = gx_s[b] = gy_s[b] = i1_s[b] = 0.0;                      // pass 2 starts on virtual chunks; its first real
+    }                                                                   // ones are requested a phase ahead like all others
+
 
     // ---- pass 1 on one chunk: warp, bounds, window, atomicMax into the ring  (:279-303, 358) ---------------
-    auto pass1_chunk = [&](const int win_lo, const unsigned win_span) {
-      const double pz = pz_next;                                        // :279
-      pz_next = plane_load<TD>(rD0, k1 + NW * WAVE);                    // past the plane: 0
+    auto pass1_chunk = [&](const int win_lo, const unsigned win_span, double &slot) {
+      const double pz = slot;                                           // :279
+      slot = plane_load<TD>(rD0, k1 + B * NW * WAVE);                   // this slot's chunk of the next phase (past the plane: 0)
       const double px = (cd1 - ox) * pz * ifx;                          // :282
       const double py = (rd1 - oy) * pz * ify;                          // :283
       const double X = fma(r02, pz, fma(r01, py, fma(t15, px, cx)));    // Rt*point3D  :291
@@ -177,15 +210,16 @@ __global__ __launch_bounds__(SLIDE_T, SLIDE_T / 256) void gn_level_kernel_slide(
     };
 
     // ---- pass 2 on one chunk: residual, Jacobian row, accumulation  (:308-356, 538-540) -------------------
-    auto pass2_chunk = [&](auto huber_tag, const int o, const double pixel1) {
+    auto pass2_chunk = [&](auto huber_tag, const int o, const double pixel1, double &s_pz, double &s_gx, double &s_gy,
+                           double &s_i1) {
       constexpr bool HUBER = decltype(huber_tag)::value;
-      const double pz = pz_n, gxi = gx_n, gyi = gy_n, pixel2 = i1_n;
+      const double pz = s_pz, gxi = s_gx, gyi = s_gy, pixel2 = s_i1;
       {
-        const int kk = k2 + NW * WAVE;
-        pz_n = plane_load<TD>(rD0, kk);
-        gx_n = plane_load<TI>(rGX, kk);                                 // gradient at the SOURCE index  :346-347
-        gy_n = plane_load<TI>(rGY, kk);
-        i1_n = plane_load<TI>(rI1, kk);                                 // :309
+        const int kk = k2 + B * NW * WAVE;                              // this slot's chunk of the next phase
+        s_pz = plane_load<TD>(rD0, kk);
+        s_gx = plane_load<TI>(rGX, kk);                                 // gradient at the SOURCE index  :346-347
+        s_gy = plane_load<TI>(rGY, kk);
+        s_i1 = plane_load<TI>(rI1, kk);                                 // :309
       }
       const unsigned long long mbits =
           ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(inb_hi, j2 & 63) << 32) |
@@ -235,45 +269,45 @@ __global__ __launch_bounds__(SLIDE_T, SLIDE_T / 256) void gn_level_kernel_slide(
     };
 
     // ---- the phases of this iteration ---------------------------------------------------------------------
-    for (int s = 0; s < n_bands + SLIDE_M + 1; s++) {                   // wave-uniform bounds throughout
-      const int s2 = s - (SLIDE_M + 1);
-      // owners of this phase's pass-2 band: the ring slots are final (nobody writes band s2 any more), are read and
-      // reset here, and the gathers of the owning source intensities go out before pass 1 so that they arrive under it
-      int own[B];
-      double i0v[B];
+    // (two compiled copies, with and without the Huber weights, chosen outside the loop: the reference path carries none
+    // of the extension's instructions and the 27 sums are not shuffled through a join after every chunk)
+    auto run_phases = [&](auto huber_tag) {
+    // Everything a phase consumes was requested a phase earlier: the depth of pass 1's chunks and the four planes of
+    // pass 2's (inside the chunk bodies, one chunk ahead), and -- here -- the owners of the band pass 2 takes NEXT phase
+    // together with the gathers of the source intensities they point at.
+    int own_n[B];
+    double i0_n[B];
 #pragma unroll
-      for (int b = 0; b < B; b++) { own[b] = -1; i0v[b] = 0.0; }
-      if (s2 >= 0) {
+    for (int b = 0; b < B; b++) { own_n[b] = -1; i0_n[b] = 0.0; }
+    int k3 = k0 - SLIDE_M * SLIDE_BAND_PX;                              // this wave's first pixel of the band whose owners are read
+    for (int s = 0; s < n_bands + SLIDE_M + 1; s++) {                   // wave-uniform trip count; no other branch in the body
+      int own_c[B];
+      double i0_c[B];
 #pragma unroll
-        for (int b = 0; b < B; b++) {
-          const int kk = k2 + b * NW * WAVE;
-          if (kk < n) {
-            own[b] = s_owner[kk & (SLIDE_RING_PX - 1)];
-            s_owner[kk & (SLIDE_RING_PX - 1)] = -1;                     // ready for the band that reuses this slot
-          }
-        }
+      for (int b = 0; b < B; b++) { own_c[b] = own_n[b]; i0_c[b] = i0_n[b]; }
+      // band s - M: nobody writes it any more (this phase's pass 1 reaches back to s - M + 1 only)
 #pragma unroll
-        for (int b = 0; b < B; b++) i0v[b] = plane_load<TI>(rI0, own[b]);      // :308 (owner -1: past the plane -> 0)
-      }
-      if (s < n_bands) {
-        const int win_lo = (s - SLIDE_M) * SLIDE_BAND_PX;
-        const unsigned win_span = (unsigned)((2 * SLIDE_M + 1) * SLIDE_BAND_PX);
-#pragma unroll
-        for (int b = 0; b < B; b++) {
-          if (s * SLIDE_BAND_CHUNKS + b * NW + wave < A.n_chunks) pass1_chunk(win_lo, win_span);
+      for (int b = 0; b < B; b++) {
+        const int kk = k3 + b * NW * WAVE;
+        own_n[b] = -1;
+        if ((unsigned)kk < (unsigned)n) {
+          own_n[b] = s_owner[kk & (SLIDE_RING_PX - 1)];
+          s_owner[kk & (SLIDE_RING_PX - 1)] = -1;                       // ready for the band that reuses this slot
         }
       }
-      if (s2 >= 0) {
 #pragma unroll
-        for (int b = 0; b < B; b++) {
-          if (s2 * SLIDE_BAND_CHUNKS + b * NW + wave < A.n_chunks) {
-            if (huber_on) pass2_chunk(std::true_type{}, own[b], i0v[b]);
-            else pass2_chunk(std::false_type{}, own[b], i0v[b]);
-          }
-        }
-      }
+      for (int b = 0; b < B; b++) i0_n[b] = plane_load<TI>(rI0, own_n[b]);     // :308 (owner -1: past the plane -> 0)
+      k3 += SLIDE_BAND_PX;
+      const int win_lo = (s - SLIDE_M + 1) * SLIDE_BAND_PX;
+      const unsigned win_span = (unsigned)(2 * SLIDE_M * SLIDE_BAND_PX);
+#pragma unroll
+      for (int b = 0; b < B; b++) pass1_chunk(win_lo, win_span, pzb[b]);
+#pragma unroll
+      for (int b = 0; b < B; b++) pass2_chunk(huber_tag, own_c[b], i0_c[b], pz_s[b], gx_s[b], gy_s[b], i1_s[b]);
       __syncthreads();
     }
+    };
+    if (huber_on) run_phases(std::true_type{}); else run_phases(std::false_type{});
 
     // ---- wave-level transposed butterfly, cross-wave sum, solve, update, terminate (as gn_level_kernel) ---
     reduce_stage_swap<32, false>(acc);
@@ -359,25 +393,44 @@ __global__ __launch_bounds__(SLIDE_T, SLIDE_T / 256) void gn_level_kernel_slide(
 
 }  // namespace
 
+// The instantiation: 512 threads, four chunks per wave and band.  Measured alternatives (1280x960 level 2, 2048 pairs x 5
+// iterations; the exact kernel with the owner map in HBM takes 7.78 ms): 1024 threads / one chunk (4 waves per SIMD, 128
+// registers: the fused passes spill 176 registers into the pixel loop) 47 ms; 512 threads / two chunks 6.63 ms; this one 6.41 ms.
+#define PHOVO_SLIDE_GEOM 512, 4
+
 size_t gn_slide_lds_bytes()
 {
-  return sizeof(double) * (32 + 8 + (size_t)SLIDE_NW * NRED) + sizeof(int) * (CTL_COUNT + (size_t)SLIDE_RING_PX);
+  return sizeof(double) * (32 + 8 + (size_t)(512 / WAVE) * NRED) + sizeof(int) * (CTL_COUNT + (size_t)SLIDE_RING_PX);
 }
 
-int gn_slide_window_pixels() { return SLIDE_M * SLIDE_BAND_PX; }
+int gn_slide_window_pixels() { return (SlideGeom<PHOVO_SLIDE_GEOM>::M - 1) * SlideGeom<PHOVO_SLIDE_GEOM>::BAND_PX; }
 
 hipError_t gn_prepare_slide_kernels()
 {
   hipError_t e;
-#define PHOVO_PREP_SLIDE(TI, TD)                                                                                   \
-  e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gn_level_kernel_slide<TI, TD>),                          \
+#define PHOVO_PREP_SLIDE(GEOM, TI, TD)                                                                             \
+  e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gn_level_kernel_slide<GEOM, TI, TD>),                    \
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)gn_slide_lds_bytes());                  \
   if (e != hipSuccess) return e;
-  PHOVO_PREP_SLIDE(double, double)
-  PHOVO_PREP_SLIDE(float, float)
-  PHOVO_PREP_SLIDE(__half, float)
+  PHOVO_PREP_SLIDE(PHOVO_SLIDE_GEOM, double, double)
+  PHOVO_PREP_SLIDE(PHOVO_SLIDE_GEOM, float, float)
+  PHOVO_PREP_SLIDE(PHOVO_SLIDE_GEOM, __half, float)
 #undef PHOVO_PREP_SLIDE
   return hipSuccess;
+}
+
+template <int T, int B>
+static hipError_t launch_slide_geom(const GNLevelArgs &a, int storage, int n_blocks, hipStream_t stream)
+{
+  const dim3 grid((unsigned)n_blocks), block((unsigned)T);
+  const size_t lds = gn_slide_lds_bytes();
+  switch (storage) {
+    case PHOVO_STORAGE_F64: hipLaunchKernelGGL((gn_level_kernel_slide<T, B, double, double>), grid, block, lds, stream, a); break;
+    case PHOVO_STORAGE_F32: hipLaunchKernelGGL((gn_level_kernel_slide<T, B, float, float>), grid, block, lds, stream, a); break;
+    case PHOVO_STORAGE_F16: hipLaunchKernelGGL((gn_level_kernel_slide<T, B, __half, float>), grid, block, lds, stream, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
 }
 
 hipError_t gn_launch_level_slide(const GNLevelArgs &a, int storage, int cu_count, hipStream_t stream)
@@ -385,15 +438,7 @@ hipError_t gn_launch_level_slide(const GNLevelArgs &a, int storage, int cu_count
   if (a.n_pairs <= 0) return hipSuccess;
   if (!a.resume) return hipErrorInvalidValue;
   const int n_blocks = a.n_pairs < cu_count ? a.n_pairs : cu_count;     // persistent grid, one workgroup per CU
-  const dim3 grid((unsigned)n_blocks), block((unsigned)SLIDE_T);
-  const size_t lds = gn_slide_lds_bytes();
-  switch (storage) {
-    case PHOVO_STORAGE_F64: hipLaunchKernelGGL((gn_level_kernel_slide<double, double>), grid, block, lds, stream, a); break;
-    case PHOVO_STORAGE_F32: hipLaunchKernelGGL((gn_level_kernel_slide<float, float>), grid, block, lds, stream, a); break;
-    case PHOVO_STORAGE_F16: hipLaunchKernelGGL((gn_level_kernel_slide<__half, float>), grid, block, lds, stream, a); break;
-    default: return hipErrorInvalidValue;
-  }
-  return hipGetLastError();
+  return launch_slide_geom<PHOVO_SLIDE_GEOM>(a, storage, n_blocks, stream);
 }
 
 }  // namespace phovo_hip

@@ -105,7 +105,7 @@ def main():
                                    hbm_bytes_per_launch=v * 1024.0 * ff + w * 1024.0 * wf))
     import re
     for kd in out["kernels"]:
-        m = re.search(r"gn_level_kernel<(\d+)", kd["kernel"])
+        m = re.search(r"gn_level_kernel\w*<(\d+)", kd["kernel"])
         kd["threads"] = int(m.group(1)) if m else None
         kd["workgroups"] = kd["grid_size"] // kd["threads"] if kd["threads"] else None
         kd["pairs"] = pairs
