@@ -307,7 +307,7 @@ def main():
         run_steps(eng, src, tgt, 1, use_dist, device, n_global)
         barrier()
         k2 = max(2, args.steps // 2)
-        wall2, _ = run_steps(eng, src, tgt, k2, use_dist, device, n_global)
+        wall2, lv2 = run_steps(eng, src, tgt, k2, use_dist, device, n_global)
         barrier()
         if use_dist:
             tmax = torch.tensor([wall2], dtype=torch.float64, device=device)
@@ -323,6 +323,7 @@ def main():
         ref_term = dict(value=n_global * k2 / wall2, unit="alignments/s", steps=k2,
                         mean_iterations_per_level=[float(x) for x in it2.mean(axis=0)],
                         max_iterations_per_level=[int(x) for x in it2.max(axis=0)],
+                        avg_launch_ms_per_level=[float(x) / k2 for x in lv2[:nl]],
                         iteration_histogram=hist)
 
     # ---- PCIe-inclusive figure (never `value`): raw frames in host memory -> poses --------------------------

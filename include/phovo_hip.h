@@ -209,6 +209,11 @@ int phovo_engine_set_wide_policy(phovo_engine *e, int policy);
  * by the exact kernel (owner map in HBM) for the pairs whose warp left the window.  policy: 0 = automatic (that), -1 =
  * exact kernel only.  Results are the same either way (tests/test_gpu_parity.py). */
 int phovo_engine_set_slide_policy(phovo_engine *e, int policy);
+/* With a gradient threshold (min_gradient_norm > 0) and more pairs than the GPU holds at once, a level runs as two
+ * launches: every pair for at most `cap` iterations, then the pairs still running, all started together, to their end
+ * (the few long pairs otherwise finish one per CU after the queue is empty).  Default 4; 0 = one launch.  Results are
+ * bit-identical either way: the second launch continues from the stored state with the same kernel. */
+int phovo_engine_set_iteration_cap(phovo_engine *e, int cap);
 /* 1 if `level` would run in the wide form for a batch of n_pairs under the current settings. */
 int phovo_engine_level_uses_wide(const phovo_engine *e, int level, int n_pairs);
 

@@ -88,8 +88,10 @@ struct phovo_engine {
   size_t owner_capacity = 0;
   bool owner_tagged = false;                   // d_owner holds tagged entries of the persistent kernel, not the -1 the wide form expects
   int *d_work_counters = nullptr;              // [2][PHOVO_MAX_LEVELS][QUEUES_PER_LEVEL] work-queue heads of the level launches (view into d_pairs)
-  int *d_resume = nullptr;                     // [pairs] marks of the sliding-window form (view into d_pairs)
+  int *d_handover = nullptr;                   // [PHOVO_MAX_LEVELS][pairs + 2] hand-over lists of the two-launch levels (view into d_pairs)
   int slide_policy = 0;                        // 0 automatic (where the owner map exceeds LDS), -1 never
+  int iter_cap = 4;                            // shipped thresholds, more pairs than workgroup slots: pairs still running after this
+                                               // many iterations of a level are finished by a second launch (0 = off)
   int cu_count = 256;
   void *d_wide_ws = nullptr;                   // workspace of the wide (many-workgroups-per-pair) level form
   size_t wide_ws_capacity = 0;
@@ -125,7 +127,7 @@ void free_pairs(phovo_engine *e)
   if (e->d_pairs) (void)hipFree(e->d_pairs);
   if (e->h_up) (void)hipHostFree(e->h_up);
   if (e->h_down) (void)hipHostFree(e->h_down);
-  e->d_pairs = nullptr; e->h_up = e->h_down = nullptr; e->d_work_counters = nullptr; e->d_resume = nullptr;
+  e->d_pairs = nullptr; e->h_up = e->h_down = nullptr; e->d_work_counters = nullptr; e->d_handover = nullptr;
   if (e->d_owner) (void)hipFree(e->d_owner);
   if (e->d_wide_ws) (void)hipFree(e->d_wide_ws);
   e->d_wide_ws = nullptr; e->wide_ws_capacity = 0;
@@ -166,7 +168,7 @@ bool use_wide_level(const phovo_engine *e, int n_pairs, int n_pixels)
 
 // Byte offsets of the per-launch pair data for n pairs (see phovo_engine::d_pairs); every section starts 8-byte aligned.
 struct PairLayout {
-  size_t src, tgt, states, reports, heads, resume, total;
+  size_t src, tgt, states, reports, heads, handover, handover_stride, total;
 };
 PairLayout pair_layout(int n_pairs)
 {
@@ -178,8 +180,9 @@ PairLayout pair_layout(int n_pairs)
   l.reports = l.states + sizeof(double) * 6 * (size_t)n_pairs;
   l.heads = l.reports + sizeof(phovo_pair_report) * (size_t)n_pairs;
   // two sets of heads per level: the sliding-window launch of a large level and its follow-up each drain their own queue
-  l.resume = l.heads + sizeof(int) * 2 * PHOVO_MAX_LEVELS * QUEUES_PER_LEVEL;
-  l.total = l.resume + sizeof(int) * n2;        // per-pair "continue in the exact kernel" marks of the sliding-window form
+  l.handover = l.heads + sizeof(int) * 2 * PHOVO_MAX_LEVELS * QUEUES_PER_LEVEL;
+  l.handover_stride = n2 + 2;                   // ints per level: the list of handed-over pairs and, at [n_pairs], its length
+  l.total = l.handover + sizeof(int) * l.handover_stride * PHOVO_MAX_LEVELS;
   return l;
 }
 
@@ -413,7 +416,8 @@ int phovo_engine_create(int device, phovo_engine **out)
   }
   if (he == hipSuccess) he = gn_prepare_kernels();
   if (he == hipSuccess) he = gn_prepare_slide_kernels();
-  e->slide_policy = std::getenv("PHOVO_GN_NO_SLIDE") ? -1 : 0;        // A/B switch for tools/
+  e->slide_policy = std::getenv("PHOVO_GN_NO_SLIDE") ? -1 : 0;        // A/B switches for tools/
+  if (const char *cap = std::getenv("PHOVO_GN_ITER_CAP")) e->iter_cap = std::atoi(cap) > 0 ? std::atoi(cap) : 0;
   if (he == hipSuccess) {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) e->cu_count = cus;
@@ -538,6 +542,14 @@ int phovo_engine_set_slide_policy(phovo_engine *e, int policy)
   if (!e) return fail(PHOVO_E_INVALID_ARGUMENT, "set_slide_policy: null");
   if (policy < -1 || policy > 0) return fail(PHOVO_E_INVALID_ARGUMENT, "set_slide_policy: policy must be -1 or 0");
   e->slide_policy = policy;
+  return PHOVO_OK;
+}
+
+int phovo_engine_set_iteration_cap(phovo_engine *e, int cap)
+{
+  if (!e) return fail(PHOVO_E_INVALID_ARGUMENT, "set_iteration_cap: null");
+  if (cap < 0) return fail(PHOVO_E_INVALID_ARGUMENT, "set_iteration_cap: cap must be >= 0");
+  e->iter_cap = cap;
   return PHOVO_OK;
 }
 
@@ -856,7 +868,7 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
   e->d_states = reinterpret_cast<double *>(e->d_pairs + pl.states);
   e->d_reports = reinterpret_cast<phovo_pair_report *>(e->d_pairs + pl.reports);
   e->d_work_counters = reinterpret_cast<int *>(e->d_pairs + pl.heads);
-  e->d_resume = reinterpret_cast<int *>(e->d_pairs + pl.resume);
+  e->d_handover = reinterpret_cast<int *>(e->d_pairs + pl.handover);
   std::memset(e->h_up, 0, pl.reports);
   std::memcpy(e->h_up + pl.src, source_frames, sizeof(int) * (size_t)n_pairs);
   std::memcpy(e->h_up + pl.tgt, target_frames, sizeof(int) * (size_t)n_pairs);
@@ -907,13 +919,28 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
       const bool few = n_pairs <= LATENCY_PAIRS && lv.plan_few_ok && lv.plan_few.owner_in_lds == lv.plan.owner_in_lds;
       const GNLaunchPlan &pl = few ? lv.plan_few : lv.plan;
       a.n_lds = pl.owner_in_lds ? 0 : pl.owner_lds_entries;
+      a.handover = e->d_handover + (size_t)l * pair_layout(n_pairs).handover_stride;
+      int *second_heads = e->d_work_counters + (PHOVO_MAX_LEVELS + l) * QUEUES_PER_LEVEL;
       if (!pl.owner_in_lds && e->slide_policy >= 0) {
         // Owner map too large for LDS: the sliding-window kernel first (owner ring in LDS); pairs whose warp leaves its
-        // window are marked in a.resume and continued, from the iteration they had reached, by the exact kernel right
-        // behind it -- which draws from its own queue and drops every pair that is not marked.
-        a.resume = e->d_resume;
+        // window are put on the hand-over list and continued, from the iteration they had reached, by the exact kernel
+        // right behind it, which draws from that list.
+        a.handover_mode = HANDOVER_APPEND;
         PHOVO_HIP_CHECK(gn_launch_level_slide(a, e->ext.plane_storage, e->cu_count, e->stream));
-        a.work_counter = e->d_work_counters + (PHOVO_MAX_LEVELS + l) * QUEUES_PER_LEVEL;
+        a.handover_mode = HANDOVER_TAKE; a.takeover_flag = PHOVO_PAIR_WINDOW_FALLBACK;
+        a.work_counter = second_heads; a.n_queues = 1;
+      } else if (e->iter_cap > 0 && a.min_grad_norm > 0.0 && a.max_iter > e->iter_cap &&
+                 n_pairs > e->cu_count * pl.wgs_per_cu) {
+        // Data-dependent termination with more pairs than workgroup slots: most pairs stop after a few iterations, a few
+        // run to max_num_iterations, and whichever of those a workgroup draws late finishes alone on its CU long after
+        // the queue is empty (the launch then ends with one pair per CU at that CU's own fp64 rate).  So the first
+        // launch caps every pair at iter_cap iterations and hands the unfinished ones over; the second launch starts
+        // all of them at once, each from its stored state and iteration count -- same kernel, same arithmetic, same
+        // result bit for bit (tests/test_gpu_parity.py::test_iteration_cap_hand_over_is_bit_identical).
+        a.handover_mode = HANDOVER_APPEND; a.iter_cap = e->iter_cap;
+        PHOVO_HIP_CHECK(gn_launch_level(a, pl, e->ext.plane_storage, e->cu_count, e->stream));
+        a.handover_mode = HANDOVER_TAKE; a.iter_cap = 0; a.takeover_flag = 0;
+        a.work_counter = second_heads; a.n_queues = 1;
       }
       PHOVO_HIP_CHECK(gn_launch_level(a, pl, e->ext.plane_storage, e->cu_count, e->stream));
       if (!pl.owner_in_lds) e->owner_tagged = true;          // tagged entries stay behind (the kernel wipes per pair)
@@ -1000,6 +1027,13 @@ int phovo_engine_level_launch_info(const phovo_engine *e, int level, int *thread
   if (e->n_frames == 0) return fail(PHOVO_E_NOT_READY, "no frame pool reserved");
   const LevelPool &lv = e->levels[level];
   if (!lv.plan_ok) return fail(PHOVO_E_SHAPE, "level too large for the device path");
+  if (!lv.plan.owner_in_lds && e->slide_policy >= 0) {       // the sliding-window kernel runs first on such a level
+    if (threads) *threads = 512;
+    if (lds_bytes) *lds_bytes = (int)gn_slide_lds_bytes();
+    if (owner_in_lds) *owner_in_lds = 0;                     // a ring of 32768 entries, not the whole map
+    if (source_in_lds) *source_in_lds = 0;
+    return PHOVO_OK;
+  }
   if (threads) *threads = lv.plan.threads;
   if (lds_bytes) *lds_bytes = lv.plan.lds_bytes;
   if (owner_in_lds) *owner_in_lds = lv.plan.owner_in_lds ? 1 : 0;

@@ -75,9 +75,8 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
   // the iteration loop and the barrier at the head of the work loop is one if-block (two adjacent `if (tid == 0)`
   // blocks, one either side of the back edge, were threaded together by the compiler into a loop that reached that
   // barrier with thread 0 parked: a hang).
-  // (HUGE variant as the follow-up of the sliding-window kernel, A.resume != nullptr: only the pairs marked there)
-  if (tid == 0) s_ctl[CTL_PAIR] = OWNER_LDS ? draw_pair(A.work_counter, A.n_queues, A.n_pairs)
-                                            : draw_pair_resume(A.work_counter, A.n_queues, A.n_pairs, A.resume);
+  // (draw_pair_any: in HANDOVER_TAKE mode the pairs come from the list an earlier launch of this level left behind)
+  if (tid == 0) s_ctl[CTL_PAIR] = draw_pair_any(A);
   for (;;) {
   // The ticket thread 0 has just stored must have LEFT its LDS queue before any wave is released: the compiler omits
   // the wait in front of this one barrier (it relies on LDS operations being ordered across waves), and on the GPU
@@ -143,10 +142,9 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
   const RowColStep rc_step = make_rowcol_step(step_r, step_c, W);
   const double cd0 = (double)c0, rd0 = (double)r0;
 
-  int iteration = 0;
-  if constexpr (!OWNER_LDS) {       // continuing a pair the sliding-window kernel handed over: its completed iterations count
-    if (A.resume) iteration = __builtin_amdgcn_readfirstlane(A.reports[pair].iterations[A.level]);
-  }
+  int iteration = 0;                // continuing a pair an earlier launch handed over: its completed iterations count
+  if (A.handover_mode == HANDOVER_TAKE) iteration = __builtin_amdgcn_readfirstlane(A.reports[pair].iterations[A.level]);
+  bool handed_over = false;
   double last_gnorm = 0.0;
 #ifdef PHOVO_STAMPS
   unsigned long long st_sum[5] = {0, 0, 0, 0, 0};
@@ -482,13 +480,16 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
       if (it >= A.max_iter) done = true;                                                // :383
       else if (gnorm < A.min_grad_norm) done = true;                                    // :388
       if (!finite) done = true;     // the reference would keep iterating on NaN; the result is the same NaN
+      // HANDOVER_APPEND with a cap: a pair still running after iter_cap iterations leaves this launch here (state and
+      // pose constants are stored as for any other iteration) and is continued by the next launch of the level
+      const bool hand = !done && A.handover_mode == HANDOVER_APPEND && A.iter_cap > 0 && it >= A.iter_cap;
       PHOVO_SUBSTAMP(1)
       if (!done) write_pose_constants(st[0], st[1], st[2], st[3], st[4], st[5], s_cst, lane);   // wave-uniform branch
       PHOVO_SUBSTAMP(2)
       if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < 6; i++) s_state[i] = st[i];
-        s_ctl[CTL_DONE] = done ? 1 : 0;
+        s_ctl[CTL_DONE] = done ? 1 : (hand ? 2 : 0);
         if (!finite) s_ctl[CTL_FLAGS] |= (int)PHOVO_PAIR_NONFINITE;
       }
       last_gnorm = gnorm;
@@ -496,7 +497,8 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
     __syncthreads();
     PHOVO_STAMP(4)
     iteration++;
-    if (s_ctl[CTL_DONE]) break;
+    const int done_word = s_ctl[CTL_DONE];
+    if (done_word) { handed_over = done_word == 2; break; }
   }
 
   // ---- epilogue: state and report back to HBM -------------------------------------------------
@@ -507,9 +509,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
       A.reports[pair].iterations[A.level] = iteration;
       A.reports[pair].gradient_norm = last_gnorm;
       A.reports[pair].flags |= (uint32_t)s_ctl[CTL_FLAGS];
-      if constexpr (!OWNER_LDS) {
-        if (A.resume) A.reports[pair].flags |= PHOVO_PAIR_WINDOW_FALLBACK;
-      }
+      if (A.handover_mode == HANDOVER_TAKE) A.reports[pair].flags |= A.takeover_flag;
 #ifdef PHOVO_STAMPS
       // diagnostic build only: phase cycle sums of wave 0 go to the otherwise unused report slots 8..12
       for (int j = 0; j < 5; j++) A.reports[pair].iterations[8 + j] = (int)(st_sum[j] / (unsigned long long)iteration);
@@ -520,11 +520,8 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
       A.reports[pair].iterations[15] = (int)blockIdx.x;
 #endif
     }
-    if constexpr (!OWNER_LDS) {
-      if (A.resume) A.resume[pair] = 0;         // taken care of (a later level may mark the pair again)
-    }
-    s_ctl[CTL_PAIR] = OWNER_LDS ? draw_pair(A.work_counter, A.n_queues, A.n_pairs)
-                                : draw_pair_resume(A.work_counter, A.n_queues, A.n_pairs, A.resume);
+    if (handed_over) handover_append(A, pair);
+    s_ctl[CTL_PAIR] = draw_pair_any(A);
   }
   }   // next pair
 }

@@ -16,7 +16,7 @@
 //     are gathered, a whole phase before pass 2 needs them -- and band s - 8 is consumed by pass 2.  Rotations and
 //     translations of the sizes Gauss-Newton steps take move a pixel by a few rows; 6 bands are 38 rows at 320 px width.
 //   * a source pixel whose target falls OUTSIDE the window sets a flag.  The iteration is then void: the state is left
-//     as it was, the pair is marked in GNLevelArgs::resume and the engine's follow-up launch of gn_level_kernel (HBM
+//     as it was, the pair is put on GNLevelArgs::handover and the engine's follow-up launch of gn_level_kernel (HBM
 //     owner map, exact for any motion) continues that pair from the same iteration.  Results are therefore exactly
 //     the reference's whatever the motion; only the speed depends on the window.
 //
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(T, T / 256) void gn_level_kernel_slide(const GNLeve
       A.reports[pair].gradient_norm = last_gnorm;
       A.reports[pair].flags |= (uint32_t)s_ctl[CTL_FLAGS];
     }
-    if (handed_over) A.resume[pair] = 1;
+    if (handed_over) handover_append(A, pair);
     s_ctl[CTL_PAIR] = draw_pair(A.work_counter, A.n_queues, A.n_pairs);
   }
   }   // next pair
@@ -436,7 +436,7 @@ static hipError_t launch_slide_geom(const GNLevelArgs &a, int storage, int n_blo
 hipError_t gn_launch_level_slide(const GNLevelArgs &a, int storage, int cu_count, hipStream_t stream)
 {
   if (a.n_pairs <= 0) return hipSuccess;
-  if (!a.resume) return hipErrorInvalidValue;
+  if (!a.handover || a.handover_mode != HANDOVER_APPEND) return hipErrorInvalidValue;
   const int n_blocks = a.n_pairs < cu_count ? a.n_pairs : cu_count;     // persistent grid, one workgroup per CU
   return launch_slide_geom<PHOVO_SLIDE_GEOM>(a, storage, n_blocks, stream);
 }

@@ -103,6 +103,7 @@ SYMBOLS = {
     "phovo_engine_set_depth_range": (C.c_int, [_vp, C.c_double, C.c_double]),
     "phovo_engine_set_build_all_levels": (C.c_int, [_vp, C.c_int]),
     "phovo_engine_set_wide_policy": (C.c_int, [_vp, C.c_int]),
+    "phovo_engine_set_iteration_cap": (C.c_int, [_vp, C.c_int]),
     "phovo_engine_set_slide_policy": (C.c_int, [_vp, C.c_int]),
     "phovo_engine_level_uses_wide": (C.c_int, [_vp, C.c_int, C.c_int]),
     "phovo_engine_reserve_frames": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),

@@ -206,6 +206,11 @@ class AlignmentEngine:
         """0 automatic, 1 wide form wherever possible, -1 persistent form only."""
         check(self._lib.phovo_engine_set_wide_policy(self._h, int(policy)), "phovo_engine_set_wide_policy")
 
+    def set_iteration_cap(self, cap):
+        """Shipped thresholds, large batches: pairs still running after `cap` iterations of a level are finished by a
+        second launch (default 4; 0 = one launch).  Results are bit-identical either way."""
+        check(self._lib.phovo_engine_set_iteration_cap(self._h, int(cap)), "phovo_engine_set_iteration_cap")
+
     def set_slide_policy(self, policy):
         """0 automatic (sliding-window kernel on levels whose owner map exceeds LDS), -1 exact kernel only."""
         check(self._lib.phovo_engine_set_slide_policy(self._h, int(policy)), "phovo_engine_set_slide_policy")

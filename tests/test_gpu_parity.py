@@ -597,7 +597,7 @@ def test_batched_upload_equals_per_frame_upload():
     ((80, 60), dict(threads=256, owner_in_lds=True, source_in_lds=False)),      # QUAD: 4 workgroups per CU
     ((160, 120), dict(threads=512, owner_in_lds=True, source_in_lds=False)),    # MID: 2 workgroups per CU
     ((200, 152), dict(threads=1024, owner_in_lds=True, source_in_lds=False)),   # WIDE: one 1024-thread workgroup
-    ((320, 240), dict(threads=1024, owner_in_lds=False, source_in_lds=False)),  # HUGE: owner map in HBM
+    ((320, 240), dict(threads=512, owner_in_lds=False, source_in_lds=False)),   # SLIDE: owner ring in LDS (+ HUGE: map in HBM)
 ])
 def test_every_kernel_variant_matches_oracle(size, expect):
     """One single-level problem per launch geometry of gn_plan_level, each checked against the oracle."""
@@ -735,6 +735,50 @@ def test_exact_half_pixel_projections_on_the_device(sign, size, pairs):
     for k in range(pairs):
         assert list(reps[k].iterations[:1]) == [1] and reps[k].flags == 0
         assert se3.state_distance(s[k], es) < POSE_TOL, (k, se3.state_distance(s[k], es))
+
+
+def test_iteration_cap_hand_over_is_bit_identical():
+    """With the shipped thresholds and more pairs than workgroup slots a level runs as two launches: every pair for at most
+    `cap` iterations, then the unfinished ones from their stored state (engine.cpp).  The second
+    launch is the same kernel continuing the same arithmetic, so 2500 mixed pairs -- problems that stop after 1-3
+    iterations next to ones that need the whole budget -- must come out bit for bit the same with the hand-over off
+    (cap 0), at the default cap and at a cap of 1 (every pair that iterates twice is handed over), with identical
+    iteration counts and gradient norms, and equal to the oracle (...Analytic.h:376-392,547-549)."""
+    ncfg = native.read_config_file(os.path.join(CFG_DIR, "config_4_level_optimization_analytic.yml"))
+    nl = ncfg.num_levels
+    max_iter, min_grad = list(ncfg.max_num_iterations[:nl]), list(ncfg.min_gradient_norm[:nl])
+    _, ocfg = _cfgs(nl, max_iter, min_grad)
+    probs = [synthetic.make_pair(21, 640, 480, holes=0.02, trans=0.004, rot=0.002),
+             synthetic.make_pair(22, 640, 480, holes=0.0, trans=0.03, rot=0.015),
+             synthetic.make_pair(23, 640, 480, holes=0.05, trans=0.06, rot=0.03),
+             synthetic.make_pair(24, 640, 480, holes=0.01, trans=0.09, rot=0.05)]
+    expect = [oracle.align_frames(ocfg, p["K"], p["gray0"], p["depth0"], p["gray1"]) for p in probs]
+    its = [e[1] for e in expect]
+    assert max(i[2] for i in its) > 4 or max(i[3] for i in its) > 4, its      # somebody outlives the default cap
+    order = np.random.RandomState(9).randint(0, len(probs), size=2500)
+    src, tgt = [2 * int(i) for i in order], [2 * int(i) + 1 for i in order]
+    out = {}
+    with odometry.AlignmentEngine() as eng:
+        eng.set_config(ncfg)
+        eng.set_intrinsic_matrix(probs[0]["K"])
+        eng.reserve_frames(2 * len(probs), 640, 480)
+        for i, p in enumerate(probs):
+            eng.upload_frame(2 * i, p["gray0"], p["depth0"], roles=native.ROLE_SOURCE)
+            eng.upload_frame(2 * i + 1, p["gray1"], None, roles=native.ROLE_TARGET)
+        for cap in (0, 4, 1, 7):
+            eng.set_iteration_cap(cap)
+            out[cap] = eng.align_pairs(src, tgt, want_reports=True)
+    s0, r0 = out[0]
+    for pos, i in enumerate(order):
+        es, eits = expect[int(i)]
+        assert list(r0[pos].iterations[:nl]) == eits
+        assert se3.state_distance(s0[pos], es) < POSE_TOL
+    for cap in (4, 1, 7):
+        sc, rc = out[cap]
+        assert np.array_equal(sc, s0), cap
+        for pos in range(len(order)):
+            assert list(rc[pos].iterations[:nl]) == list(r0[pos].iterations[:nl]), (cap, pos)
+            assert rc[pos].gradient_norm == r0[pos].gradient_norm and rc[pos].flags == r0[pos].flags == 0
 
 
 def test_randomised_sweep_against_oracle():
