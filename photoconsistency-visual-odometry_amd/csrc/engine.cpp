@@ -39,6 +39,8 @@ struct LevelPool {
   bool plan_ok = false;
   GNLaunchPlan plan_few{};             // geometry for a handful of pairs (LATENCY_PAIRS or fewer)
   bool plan_few_ok = false;
+  GNLaunchPlan plan_tail{};            // geometry of the second launch of a capped level (few long pairs, one per CU)
+  bool plan_tail_ok = false;
 };
 
 }  // namespace phovo_hip
@@ -90,6 +92,7 @@ struct phovo_engine {
   int *d_work_counters = nullptr;              // [2][PHOVO_MAX_LEVELS][QUEUES_PER_LEVEL] work-queue heads of the level launches (view into d_pairs)
   int *d_handover = nullptr;                   // [PHOVO_MAX_LEVELS][pairs + 2] hand-over lists of the two-launch levels (view into d_pairs)
   int slide_policy = 0;                        // 0 automatic (where the owner map exceeds LDS), -1 never
+  bool tail_same_plan = false;                 // PHOVO_GN_TAIL_SAME_PLAN=1: second launch with the first one's geometry (A/B, tests)
   int iter_cap = 4;                            // shipped thresholds, more pairs than workgroup slots: pairs still running after this
                                                // many iterations of a level are finished by a second launch (0 = off)
   int cu_count = 256;
@@ -417,6 +420,7 @@ int phovo_engine_create(int device, phovo_engine **out)
   if (he == hipSuccess) he = gn_prepare_kernels();
   if (he == hipSuccess) he = gn_prepare_slide_kernels();
   e->slide_policy = std::getenv("PHOVO_GN_NO_SLIDE") ? -1 : 0;        // A/B switches for tools/
+  e->tail_same_plan = std::getenv("PHOVO_GN_TAIL_SAME_PLAN") != nullptr;
   if (const char *cap = std::getenv("PHOVO_GN_ITER_CAP")) e->iter_cap = std::atoi(cap) > 0 ? std::atoi(cap) : 0;
   if (he == hipSuccess) {
     int cus = 0;
@@ -587,7 +591,8 @@ int phovo_engine_reserve_frames(phovo_engine *e, int n_frames, int width, int he
     lv.n = lv.w * lv.h;
     lv.stored = e->build_all || e->cfg.max_num_iterations[l] > 0;
     lv.plan_ok = gn_plan_level(lv.n, &lv.plan);
-    lv.plan_few_ok = gn_plan_level(lv.n, &lv.plan_few, true);
+    lv.plan_few_ok = gn_plan_level(lv.n, &lv.plan_few, 1);
+    lv.plan_tail_ok = gn_plan_level(lv.n, &lv.plan_tail, 2);
     {   // byte layout of one frame at this level: planes I, D, GX, GY.  fp64: packed [4][n] doubles, which is
         // what the producer kernels write directly; narrow storages: every plane starts 16-byte aligned.
       const bool packed = e->ext.plane_storage == PHOVO_STORAGE_F64;
@@ -941,6 +946,13 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
         PHOVO_HIP_CHECK(gn_launch_level(a, pl, e->ext.plane_storage, e->cu_count, e->stream));
         a.handover_mode = HANDOVER_TAKE; a.iter_cap = 0; a.takeover_flag = 0;
         a.work_counter = second_heads; a.n_queues = 1;
+        // the pairs that are left each need many iterations: the geometry that runs ONE pair fastest
+        if (!e->tail_same_plan && lv.plan_tail_ok && lv.plan_tail.owner_in_lds) {
+          PHOVO_HIP_CHECK(gn_launch_level(a, lv.plan_tail, e->ext.plane_storage, e->cu_count, e->stream));
+          PHOVO_HIP_CHECK(hipEventRecord(e->ev_stop[l], e->stream));
+          e->level_launched[l] = true;
+          continue;
+        }
       }
       PHOVO_HIP_CHECK(gn_launch_level(a, pl, e->ext.plane_storage, e->cu_count, e->stream));
       if (!pl.owner_in_lds) e->owner_tagged = true;          // tagged entries stay behind (the kernel wipes per pair)

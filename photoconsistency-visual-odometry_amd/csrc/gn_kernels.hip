@@ -766,7 +766,7 @@ enum Variant { V_TINY = 0, V_MID, V_WIDE, V_HUGE, V_QUAD, V_DUO };
 
 }  // namespace
 
-bool gn_plan_level(int n, GNLaunchPlan *plan, bool prefer_latency)
+bool gn_plan_level(int n, GNLaunchPlan *plan, int prefer_latency)
 {
   plan->owner_lds_entries = 0;
   const size_t n_chunks = (size_t)(n + WAVE - 1) / WAVE;
@@ -798,7 +798,9 @@ bool gn_plan_level(int n, GNLaunchPlan *plan, bool prefer_latency)
   const size_t f512 = lds_fixed_bytes(512), f1024 = lds_fixed_bytes(1024);
   const bool reg512 = n_chunks <= 64 * 8, reg1024 = n_chunks <= 64 * 16;
   static const bool force_wide = std::getenv("PHOVO_GN_FORCE_WIDE") != nullptr;     // tuning aid
-  if (!force_wide && reg512 && f512 + owner <= LDS_HALF) {
+  // prefer_latency == 2: the widest workgroup that keeps the owner map in LDS (a pair alone on its CU: 16 waves instead of 8)
+  const bool widest = prefer_latency >= 2 && reg1024 && f1024 + owner <= LDS_LIMIT && n_chunks >= 64;
+  if (!force_wide && !widest && reg512 && f512 + owner <= LDS_HALF) {
     plan->variant = V_MID; plan->threads = 512; plan->wgs_per_cu = 2; plan->owner_in_lds = true; plan->source_in_lds = false;
     plan->lds_bytes = (int)(f512 + owner);
     return true;

@@ -737,13 +737,15 @@ def test_exact_half_pixel_projections_on_the_device(sign, size, pairs):
         assert se3.state_distance(s[k], es) < POSE_TOL, (k, se3.state_distance(s[k], es))
 
 
-def test_iteration_cap_hand_over_is_bit_identical():
+def test_iteration_cap_hand_over_leaves_results_unchanged(monkeypatch):
     """With the shipped thresholds and more pairs than workgroup slots a level runs as two launches: every pair for at most
-    `cap` iterations, then the unfinished ones from their stored state (engine.cpp).  The second
-    launch is the same kernel continuing the same arithmetic, so 2500 mixed pairs -- problems that stop after 1-3
-    iterations next to ones that need the whole budget -- must come out bit for bit the same with the hand-over off
-    (cap 0), at the default cap and at a cap of 1 (every pair that iterates twice is handed over), with identical
-    iteration counts and gradient norms, and equal to the oracle (...Analytic.h:376-392,547-549)."""
+    `cap` iterations, then the unfinished ones, all started together, from their stored state and iteration count
+    (engine.cpp).  2500 mixed pairs -- problems that stop after 1-3 iterations next to ones that
+    need more than the cap -- with the hand-over off (cap 0), at the default cap, at a cap of 1 (every pair that iterates
+    twice is handed over) and at 7: identical iteration counts everywhere, every copy of a problem bit-identical within a
+    run, poses equal to the oracle (...Analytic.h:376-392,547-549).  The second launch takes the geometry that runs one pair
+    fastest (1024 threads where the first had 512 or 256), so between caps the sums differ in their last bits (same bar as
+    against the oracle); with PHOVO_GN_TAIL_SAME_PLAN=1 it is the same kernel and everything is bit for bit the same."""
     ncfg = native.read_config_file(os.path.join(CFG_DIR, "config_4_level_optimization_analytic.yml"))
     nl = ncfg.num_levels
     max_iter, min_grad = list(ncfg.max_num_iterations[:nl]), list(ncfg.min_gradient_norm[:nl])
@@ -757,28 +759,38 @@ def test_iteration_cap_hand_over_is_bit_identical():
     assert max(i[2] for i in its) > 4 or max(i[3] for i in its) > 4, its      # somebody outlives the default cap
     order = np.random.RandomState(9).randint(0, len(probs), size=2500)
     src, tgt = [2 * int(i) for i in order], [2 * int(i) + 1 for i in order]
-    out = {}
-    with odometry.AlignmentEngine() as eng:
-        eng.set_config(ncfg)
-        eng.set_intrinsic_matrix(probs[0]["K"])
-        eng.reserve_frames(2 * len(probs), 640, 480)
-        for i, p in enumerate(probs):
-            eng.upload_frame(2 * i, p["gray0"], p["depth0"], roles=native.ROLE_SOURCE)
-            eng.upload_frame(2 * i + 1, p["gray1"], None, roles=native.ROLE_TARGET)
-        for cap in (0, 4, 1, 7):
-            eng.set_iteration_cap(cap)
-            out[cap] = eng.align_pairs(src, tgt, want_reports=True)
-    s0, r0 = out[0]
-    for pos, i in enumerate(order):
-        es, eits = expect[int(i)]
-        assert list(r0[pos].iterations[:nl]) == eits
-        assert se3.state_distance(s0[pos], es) < POSE_TOL
-    for cap in (4, 1, 7):
-        sc, rc = out[cap]
-        assert np.array_equal(sc, s0), cap
-        for pos in range(len(order)):
-            assert list(rc[pos].iterations[:nl]) == list(r0[pos].iterations[:nl]), (cap, pos)
-            assert rc[pos].gradient_norm == r0[pos].gradient_norm and rc[pos].flags == r0[pos].flags == 0
+
+    def run(caps):
+        out = {}
+        with odometry.AlignmentEngine() as eng:
+            eng.set_config(ncfg)
+            eng.set_intrinsic_matrix(probs[0]["K"])
+            eng.reserve_frames(2 * len(probs), 640, 480)
+            for i, p in enumerate(probs):
+                eng.upload_frame(2 * i, p["gray0"], p["depth0"], roles=native.ROLE_SOURCE)
+                eng.upload_frame(2 * i + 1, p["gray1"], None, roles=native.ROLE_TARGET)
+            for cap in caps:
+                eng.set_iteration_cap(cap)
+                out[cap] = eng.align_pairs(src, tgt, want_reports=True)
+        return out
+
+    out = run((0, 4, 1, 7))
+    first = {int(i): pos for pos, i in reversed(list(enumerate(order)))}
+    for cap, (sc, rc) in out.items():
+        for pos, i in enumerate(order):
+            es, eits = expect[int(i)]
+            assert list(rc[pos].iterations[:nl]) == eits, (cap, pos)
+            assert rc[pos].flags == 0
+            assert np.array_equal(sc[pos], sc[first[int(i)]]), (cap, pos)            # position and history do not matter
+        for i, pos in first.items():
+            assert se3.state_distance(sc[pos], expect[i][0]) < POSE_TOL, (cap, i)
+    # the same kernel in both launches: bit for bit whatever the cap
+    monkeypatch.setenv("PHOVO_GN_TAIL_SAME_PLAN", "1")
+    same = run((0, 4, 1))
+    for cap in (4, 1):
+        assert np.array_equal(same[cap][0], same[0][0]), cap
+        assert all(a.gradient_norm == b.gradient_norm for a, b in zip(same[cap][1], same[0][1]))
+    assert np.array_equal(same[0][0], out[0][0])
 
 
 def test_randomised_sweep_against_oracle():
