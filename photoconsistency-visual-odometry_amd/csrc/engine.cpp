@@ -934,14 +934,15 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
         PHOVO_HIP_CHECK(gn_launch_level_slide(a, e->ext.plane_storage, e->cu_count, e->stream));
         a.handover_mode = HANDOVER_TAKE; a.takeover_flag = PHOVO_PAIR_WINDOW_FALLBACK;
         a.work_counter = second_heads; a.n_queues = 1;
-      } else if (e->iter_cap > 0 && a.min_grad_norm > 0.0 && a.max_iter > e->iter_cap &&
-                 n_pairs > e->cu_count * pl.wgs_per_cu) {
-        // Data-dependent termination with more pairs than workgroup slots: most pairs stop after a few iterations, a few
-        // run to max_num_iterations, and whichever of those a workgroup draws late finishes alone on its CU long after
-        // the queue is empty (the launch then ends with one pair per CU at that CU's own fp64 rate).  So the first
-        // launch caps every pair at iter_cap iterations and hands the unfinished ones over; the second launch starts
-        // all of them at once, each from its stored state and iteration count -- same kernel, same arithmetic, same
-        // result bit for bit (tests/test_gpu_parity.py::test_iteration_cap_hand_over_is_bit_identical).
+      } else if (e->iter_cap > 0 && a.min_grad_norm > 0.0 && a.max_iter > e->iter_cap && !few) {
+        // Data-dependent termination: most pairs stop after a few iterations, a few run to max_num_iterations, and
+        // whichever of those a workgroup draws late finishes alone on its CU long after the queue is empty (the launch
+        // then ends with one pair per CU at that CU's own fp64 rate).  So the first launch caps every pair at iter_cap
+        // iterations and hands the unfinished ones over; the second launch starts all of them at once, each from its
+        // stored state and iteration count, in the geometry that runs one pair fastest.  Every batch the persistent
+        // kernel takes in its throughput geometry goes this way, whatever its size, so that a pair's result does not
+        // depend on how many other pairs were aligned with it (a sequence gives the same trajectory file, byte for
+        // byte, on 1, 2 or 3 ranks: tests/test_sequence_sharded.py).
         a.handover_mode = HANDOVER_APPEND; a.iter_cap = e->iter_cap;
         PHOVO_HIP_CHECK(gn_launch_level(a, pl, e->ext.plane_storage, e->cu_count, e->stream));
         a.handover_mode = HANDOVER_TAKE; a.iter_cap = 0; a.takeover_flag = 0;

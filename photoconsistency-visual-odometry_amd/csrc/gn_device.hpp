@@ -197,6 +197,9 @@ __device__ __forceinline__ double plane_load<__half>(__amdgpu_buffer_rsrc_t r, i
 // that follow (tests/test_gpu_parity.py holds the poses to 1e-9 against the oracle's exact divisions).
 __device__ __forceinline__ double fast_rcp(double x)
 {
+#ifdef PHOVO_AB_IEEE_DIV          // A/B diagnostic build only (divergence class): the correctly rounded quotient
+  return 1.0 / x;
+#endif
   double r = __builtin_amdgcn_rcp(x);
   double e = fma(-x, r, 1.0);
   r = fma(r, e, r);
