@@ -3,10 +3,13 @@ half-integers, depth holes / NaN / out-of-range depth, large motions, non-zero i
 the sizes select, optionally narrow storage / Huber / bilinear.  Prints one line per failure and a summary; exit code 1
 if any case misses the 1e-9 pose bar or an iteration count.
 
-    python tools/fuzz_parity.py [cases=150] [seed=0] [ext]
+    python tools/fuzz_parity.py [cases=150] [seed=0] [ext] [big]
 
 With `ext` every case also draws a combination of the opt-in extensions (fp32 / fp16 plane storage, Huber weights,
 bilinear sampling with or without the corrected Jacobian); the oracle is then fed the planes as the device stored them.
+With `big` the images are 240x200 ... 700x500 with 1-2 levels, 40 or 300 pairs and in-plane rotations of up to 0.25 rad:
+level 0 then exceeds what an owner map in LDS holds, i.e. the sliding-window kernel and, for the large rotations, its
+hand-over to the exact kernel (PHOVO_PAIR_WINDOW_FALLBACK) are what is being swept.
 """
 import os
 import sys
@@ -20,16 +23,18 @@ from oracle import oracle  # noqa: E402
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-with_ext = len(sys.argv) > 3 and sys.argv[3] == "ext"
-bad, worst, variants = 0, 0.0, {}
+with_ext = "ext" in sys.argv[3:]
+big = "big" in sys.argv[3:]
+bad, worst, variants, fallbacks = 0, 0.0, {}, 0
 for case in range(cases):
-    nl = int(rs.randint(1, 4))
+    nl = int(rs.randint(1, 3 if big else 4))
     unit = 2 ** (nl - 1)
-    w = int(rs.randint(16, 330)) // unit * unit + (unit if rs.rand() < 0.5 else 0)
-    h = int(rs.randint(12, 250)) // unit * unit + (unit if rs.rand() < 0.5 else 0)
+    w = int(rs.randint(240, 700) if big else rs.randint(16, 330)) // unit * unit + (unit if rs.rand() < 0.5 else 0)
+    h = int(rs.randint(200, 500) if big else rs.randint(12, 250)) // unit * unit + (unit if rs.rand() < 0.5 else 0)
     w, h = max(w, 8 * unit), max(h, 8 * unit)
     p = synthetic.make_pair(1000 + case, w, h, holes=float(rs.choice([0.0, 0.02, 0.2])),
-                            trans=float(rs.choice([0.002, 0.02, 0.08])), rot=float(rs.choice([0.001, 0.01, 0.05])))
+                            trans=float(rs.choice([0.002, 0.02, 0.08])),
+                            rot=float(rs.choice([0.001, 0.01, 0.05, 0.25] if big else [0.001, 0.01, 0.05])))
     K = p["K"].copy()
     if rs.rand() < 0.6:                     # principal point / focal lengths that are not exactly representable
         K[0, 2] += rs.uniform(-3, 3)
@@ -82,7 +87,7 @@ for case in range(cases):
                     lst.append(v)
             es, eits = oracle.optimize(ocfg, K, *planes, init_state=init, huber_delta=huber, bilinear=bilinear,
                                        corrected=corrected)[:2]
-        n_pairs = int(rs.choice([1, 3, 40]))          # 40 > 32: never the wide form
+        n_pairs = int(rs.choice([40, 300] if big else [1, 3, 40]))          # 40 > 32: never the wide form
         inits = None if init is None else np.tile(init, (n_pairs, 1))
         s, reps = eng.align_pairs([0] * n_pairs, [1] * n_pairs, init_states=inits, want_reports=True)
         for l in range(nl):
@@ -90,6 +95,7 @@ for case in range(cases):
                 info = eng.level_launch_info(l)
                 key = (info["threads"], info["owner_in_lds"], info["source_in_lds"], bool(eng.level_uses_wide(l, n_pairs)))
                 variants[key] = variants.get(key, 0) + 1
+    fallbacks += int(bool(reps[0].flags & native.PAIR_WINDOW_FALLBACK))
     its = list(reps[0].iterations[:nl])
     finite = np.all(np.isfinite(es))
     if finite:
@@ -97,7 +103,7 @@ for case in range(cases):
         ok = its == eits and d < 1e-9 and all(np.array_equal(s[0], s[i]) for i in range(n_pairs))
     else:                                   # the oracle ran into NaN (no valid pixel / singular H): flagged, not hidden
         d = 0.0
-        ok = bool(reps[0].flags) and not np.all(np.isfinite(s[0]))
+        ok = bool(reps[0].flags & native.PAIR_NONFINITE) and not np.all(np.isfinite(s[0]))
     worst = max(worst, d)
     if not ok:
         bad += 1
@@ -105,5 +111,6 @@ for case in range(cases):
               f"iterations gpu {its} cpu {eits} distance {d:.3e} flags {reps[0].flags} "
               f"ext(storage {storage}, huber {huber}, bilinear {bilinear}, corrected {corrected})")
 print(f"{cases} cases, {bad} failures, worst pose distance {worst:.3e}")
+print(f"pairs finished by the exact kernel after leaving the sliding window: {fallbacks} cases")
 print("launch geometries exercised (threads, owner in LDS, source in LDS, wide form): ", variants)
 sys.exit(1 if bad else 0)
