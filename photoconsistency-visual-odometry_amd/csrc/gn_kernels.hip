@@ -448,7 +448,9 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
       PHOVO_SUBSTAMP_BEGIN
       // lane l sums value (l & 31) over half of the waves, the halves meet in one shuffle
       double v = 0.0;
-      {
+      if constexpr (NW == 1) {
+        v = s_red[lane & (NRED - 1)];                     // a single wave: its own row is the total
+      } else {
         const int j = lane & (NRED - 1);
         const int w0 = (lane >> 5) * (NW / 2);
 #pragma unroll
@@ -754,7 +756,7 @@ static_assert((1 << OWNER_TAG_SHIFT) - 1 == OWNER_INDEX_MASK, "index mask and ta
 //   HUGE   1024 threads, owner map in global memory, ballot mask in LDS
 //   TINY   256 threads, 4 workgroups/CU, everything in LDS (levels of <= 2048 pixels)
 //   QUAD   256 threads, 4 workgroups/CU, owner map in LDS, source intensity gathered from L2
-enum Variant { V_TINY = 0, V_MID, V_WIDE, V_HUGE, V_QUAD, V_DUO };
+enum Variant { V_TINY = 0, V_MID, V_WIDE, V_HUGE, V_QUAD, V_DUO, V_SOLO };
 
 // ... times the three plane storages (fp64 = reference-exact; fp32; fp16 images + fp32 depth).
 #define PHOVO_KERNEL_TINY(TI, TD)  gn_level_kernel<256, 4, true, true, true, TI, TD>
@@ -763,6 +765,7 @@ enum Variant { V_TINY = 0, V_MID, V_WIDE, V_HUGE, V_QUAD, V_DUO };
 #define PHOVO_KERNEL_HUGE(TI, TD)  gn_level_kernel<1024, 4, false, false, false, TI, TD>
 #define PHOVO_KERNEL_QUAD(TI, TD)  gn_level_kernel<256, 4, false, true, true, TI, TD>
 #define PHOVO_KERNEL_DUO(TI, TD)   gn_level_kernel<512, 4, true, true, true, TI, TD>
+#define PHOVO_KERNEL_SOLO(TI, TD)  gn_level_kernel<64, 4, false, true, true, TI, TD>
 
 }  // namespace
 
@@ -772,6 +775,16 @@ bool gn_plan_level(int n, GNLaunchPlan *plan, int prefer_latency)
   const size_t n_chunks = (size_t)(n + WAVE - 1) / WAVE;
   const size_t owner = sizeof(int) * (size_t)((n + 1) & ~1);
   const size_t src = sizeof(double) * (size_t)n;
+  // Levels of <= 2048 pixels in a throughput launch: ONE WAVE per pair, 16 workgroups per CU.  An iteration of such a level
+  // is short (40x30: 19 chunks) and a third of a 256-thread workgroup's time per iteration is wave 0's serial section
+  // (solve, sincos, pose constants) with the other three waves waiting at the barrier; with one wave per pair nobody
+  // waits -- the other 15 pairs of the CU fill the SIMDs meanwhile.  PHOVO_GN_NO_SOLO=1: A/B switch for tools/.
+  static const bool no_solo = std::getenv("PHOVO_GN_NO_SOLO") != nullptr;
+  if (n <= 2048 && !prefer_latency && !no_solo && n_chunks <= 64) {
+    plan->variant = V_SOLO; plan->threads = 64; plan->wgs_per_cu = 16; plan->owner_in_lds = true; plan->source_in_lds = false;
+    plan->lds_bytes = (int)(lds_fixed_bytes(64) + owner);
+    return true;
+  }
   if (n <= 2048) {
     plan->variant = V_TINY; plan->threads = 256; plan->wgs_per_cu = 4; plan->owner_in_lds = true; plan->source_in_lds = true;
     plan->lds_bytes = (int)(lds_fixed_bytes(256) + owner + src);
@@ -837,6 +850,7 @@ hipError_t prepare_storage()
   PHOVO_PREP(PHOVO_KERNEL_HUGE)
   PHOVO_PREP(PHOVO_KERNEL_QUAD)
   PHOVO_PREP(PHOVO_KERNEL_DUO)
+  PHOVO_PREP(PHOVO_KERNEL_SOLO)
 #undef PHOVO_PREP
   return hipSuccess;
 }
@@ -853,6 +867,7 @@ hipError_t launch_storage(const GNLevelArgs &a, const GNLaunchPlan &plan, int n_
     case V_HUGE:  hipLaunchKernelGGL(PHOVO_KERNEL_HUGE(TI, TD), grid, block, lds, stream, a); break;
     case V_QUAD:  hipLaunchKernelGGL(PHOVO_KERNEL_QUAD(TI, TD), grid, block, lds, stream, a); break;
     case V_DUO:   hipLaunchKernelGGL(PHOVO_KERNEL_DUO(TI, TD), grid, block, lds, stream, a); break;
+    case V_SOLO:  hipLaunchKernelGGL(PHOVO_KERNEL_SOLO(TI, TD), grid, block, lds, stream, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -593,7 +593,8 @@ def test_batched_upload_equals_per_frame_upload():
 
 
 @pytest.mark.parametrize("size,expect", [
-    ((40, 30), dict(threads=256, owner_in_lds=True, source_in_lds=True)),       # TINY: everything in LDS
+    ((40, 30), dict(threads=64, owner_in_lds=True, source_in_lds=False)),       # SOLO: one wave per pair, 16 per CU (TINY, 256
+                                                                                # threads with everything in LDS, for <= 8 pairs)
     ((80, 60), dict(threads=256, owner_in_lds=True, source_in_lds=False)),      # QUAD: 4 workgroups per CU
     ((160, 120), dict(threads=512, owner_in_lds=True, source_in_lds=False)),    # MID: 2 workgroups per CU
     ((200, 152), dict(threads=1024, owner_in_lds=True, source_in_lds=False)),   # WIDE: one 1024-thread workgroup

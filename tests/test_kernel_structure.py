@@ -55,6 +55,11 @@ def test_work_loop_head_is_the_barrier(kernels):
             assert not any(l.strip() == "s_barrier" for l in body[heads[0]:heads[1]]), f"{name}: barrier inside the draw loop"
             heads = heads[1:]
         assert len(heads) == 1, f"{name}: expected exactly one outermost loop (the work queue), found {len(heads)}"
+        if "gn_level_kernelILi64E" in name:
+            # one wave per workgroup: the compiler drops every workgroup barrier (a wave is in step with itself and its LDS
+            # operations execute in order), so neither hazard this test is about exists; the loop shape is still checked
+            assert not any(l.strip() == "s_barrier" for l in body), f"{name}: a barrier in a single-wave workgroup?"
+            continue
         i, waited = heads[0] + 1, False
         while True:
             t = body[i].strip()
