@@ -36,6 +36,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, ch
 WORKLOADS = {
     "cfg2": dict(yml="config_4_level_optimization_analytic.yml", size=(640, 480),
                  metric="frame-pair alignments/sec (640x480, 4-level)"),
+    "cfg3": dict(yml="config_5_level_optimization_analytic.yml", size=(640, 480),
+                 metric="frame-pair alignments/sec (640x480, 5-level: the VisualOdometry app's configuration; not the headline metric)"),
     "cfg5": dict(yml="config_6_level_optimization_analytic.yml", size=(1280, 960),
                  metric="frame-pair alignments/sec (1280x960, 6-level; not the headline metric)"),
 }
@@ -64,8 +66,9 @@ def parse():
                     help="diagnostic, never the default: comma list overriding the yml's max_num_iterations, level 0 first "
                          "(e.g. 0,0,1,1 = every plane streamed exactly once: the HBM-only rate of the level kernels)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2",
-                    help="cfg2 = the headline 640x480 4-level workload; cfg5 = BASELINE.json configs[4]'s shape "
-                         "(1280x960, config_6_level; combine with --storage f16 --huber 0.05)")
+                    help="cfg2 = the headline 640x480 4-level workload; cfg3 = BASELINE.json configs[2]'s configuration "
+                         "(640x480, config_5_level); cfg5 = configs[4]'s shape (1280x960, config_6_level; combine with "
+                         "--storage f16 --huber 0.05)")
     return ap.parse_args()
 
 
