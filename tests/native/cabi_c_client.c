@@ -30,6 +30,26 @@ int main(int argc, char **argv)
   CHECK(rt[3] == 0.1 && rt[7] == -0.2 && rt[11] == 0.3 && rt[15] == 1.0);
   CHECK(fabs(rt[0] * rt[0] + rt[4] * rt[4] + rt[8] * rt[8] - 1.0) < 1e-15);
 
+  /* the VisualOdometry app's pose chain and trajectory line (host arithmetic, ...VisualOdometry.cpp:233-243) */
+  {
+    const double two[12] = {0.1, -0.2, 0.3, 0.01, -0.02, 0.03, 0.1, -0.2, 0.3, 0.01, -0.02, 0.03};
+    double pose[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, poses[32], prod[16];
+    char line[256];
+    CHECK(phovo_trajectory_chain(2, two, pose, poses) == PHOVO_OK);
+    /* pose_1 * Rt must be the identity: pose_1 = Rt^-1 */
+    for (int i = 0; i < 4; i++)
+      for (int j = 0; j < 4; j++) {
+        prod[4 * i + j] = 0;
+        for (int k = 0; k < 4; k++) prod[4 * i + j] += poses[4 * i + k] * rt[4 * k + j];
+        CHECK(fabs(prod[4 * i + j] - (i == j ? 1.0 : 0.0)) < 1e-14);
+      }
+    CHECK(memcmp(pose, poses + 16, sizeof(pose)) == 0);
+    CHECK(phovo_trajectory_format_pose(1305031102.175304, pose, line, sizeof(line)) == PHOVO_OK);
+    CHECK(strncmp(line, "1305031102.175304 ", 18) == 0 && strlen(line) > 100);
+    CHECK(phovo_trajectory_format_pose(1.0, pose, line, 8) == PHOVO_E_INVALID_ARGUMENT);
+    CHECK(phovo_trajectory_chain(1, NULL, pose, NULL) == PHOVO_E_INVALID_ARGUMENT);
+  }
+
   if (phovo_device_count() == 0) {                  /* no GPU: the product path must refuse, not fall back */
     phovo_odometry *o = NULL;
     phovo_engine *e = NULL;
@@ -40,6 +60,8 @@ int main(int argc, char **argv)
   CHECK(phovo_odometry_optimize(NULL) == PHOVO_E_INVALID_ARGUMENT);
   CHECK(phovo_engine_align_pairs(NULL, 0, NULL, NULL, NULL, NULL, NULL) == PHOVO_E_INVALID_ARGUMENT);
   CHECK(phovo_engine_upload_frames_u16(NULL, 0, 0, 0, NULL, 0, 0, NULL, 0, 0, 1.0) == PHOVO_E_INVALID_ARGUMENT);
+  CHECK(phovo_engine_set_iteration_cap(NULL, 4) == PHOVO_E_INVALID_ARGUMENT);
+  CHECK(phovo_engine_set_slide_policy(NULL, 0) == PHOVO_E_INVALID_ARGUMENT);
   CHECK(phovo_engine_destroy(NULL) == PHOVO_OK && phovo_odometry_destroy(NULL) == PHOVO_OK);
   printf("cabi_c_client ok\n");
   return 0;
