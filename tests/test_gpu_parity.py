@@ -806,6 +806,20 @@ def test_randomised_sweep_against_oracle():
     assert "80 cases, 0 failures" in r.stdout
 
 
+def test_randomised_sweep_of_large_levels_against_oracle():
+    """tools/fuzz_parity.py in its `big` mode: 40 random problems of 240x200 ... 700x500 pixels with 1-2 levels, 40 or 300
+    pairs, in-plane rotations of up to 0.25 rad -- level 0 exceeds what an owner map in LDS holds, so this sweeps the
+    sliding-window kernel and (for the large rotations) its hand-over to the exact kernel; same bars."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "40", "11", "big"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "40 cases, 0 failures" in r.stdout
+    m = __import__("re").search(r"leaving the sliding window: (\d+) cases", r.stdout)
+    assert m and int(m.group(1)) >= 1, r.stdout[-500:]           # the sweep did reach the fallback
+
+
 def test_device_result_buffer_as_torch_tensor():
     """bench.py --gpus N starts its all_gather from the engine's device buffer: the zero-copy torch view of
     phovo_engine_results_device_ptr must hold exactly what fetch_results copies out.  Run in a fresh process with
