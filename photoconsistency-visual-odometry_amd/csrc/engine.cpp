@@ -92,6 +92,7 @@ struct phovo_engine {
   int *d_work_counters = nullptr;              // [2][PHOVO_MAX_LEVELS][QUEUES_PER_LEVEL] work-queue heads of the level launches (view into d_pairs)
   int *d_handover = nullptr;                   // [PHOVO_MAX_LEVELS][pairs + 2] hand-over lists of the two-launch levels (view into d_pairs)
   int slide_policy = 0;                        // 0 automatic (where the owner map exceeds LDS), -1 never
+  int tail_stages = 3;                         // launches of a capped level: 3 = caps at iter_cap and 3 x iter_cap (PHOVO_GN_TAIL_STAGES=2: one cap)
   bool tail_same_plan = false;                 // PHOVO_GN_TAIL_SAME_PLAN=1: second launch with the first one's geometry (A/B, tests)
   int iter_cap = 4;                            // shipped thresholds, more pairs than workgroup slots: pairs still running after this
                                                // many iterations of a level are finished by a second launch (0 = off)
@@ -182,10 +183,10 @@ PairLayout pair_layout(int n_pairs)
   l.states = l.tgt + sizeof(int) * n2;
   l.reports = l.states + sizeof(double) * 6 * (size_t)n_pairs;
   l.heads = l.reports + sizeof(phovo_pair_report) * (size_t)n_pairs;
-  // two sets of heads per level: the sliding-window launch of a large level and its follow-up each drain their own queue
-  l.handover = l.heads + sizeof(int) * 2 * PHOVO_MAX_LEVELS * QUEUES_PER_LEVEL;
+  // three sets of heads per level: every launch of a level (up to three, see enqueue) drains its own queue
+  l.handover = l.heads + sizeof(int) * 3 * PHOVO_MAX_LEVELS * QUEUES_PER_LEVEL;
   l.handover_stride = n2 + 2;                   // ints per level: the list of handed-over pairs and, at [n_pairs], its length
-  l.total = l.handover + sizeof(int) * l.handover_stride * PHOVO_MAX_LEVELS;
+  l.total = l.handover + sizeof(int) * l.handover_stride * 2 * PHOVO_MAX_LEVELS;       // two lists per level
   return l;
 }
 
@@ -421,6 +422,7 @@ int phovo_engine_create(int device, phovo_engine **out)
   if (he == hipSuccess) he = gn_prepare_slide_kernels();
   e->slide_policy = std::getenv("PHOVO_GN_NO_SLIDE") ? -1 : 0;        // A/B switches for tools/
   e->tail_same_plan = std::getenv("PHOVO_GN_TAIL_SAME_PLAN") != nullptr;
+  if (const char *st = std::getenv("PHOVO_GN_TAIL_STAGES")) e->tail_stages = std::atoi(st);
   if (const char *cap = std::getenv("PHOVO_GN_ITER_CAP")) e->iter_cap = std::atoi(cap) > 0 ? std::atoi(cap) : 0;
   if (he == hipSuccess) {
     int cus = 0;
@@ -924,36 +926,47 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
       const bool few = n_pairs <= LATENCY_PAIRS && lv.plan_few_ok && lv.plan_few.owner_in_lds == lv.plan.owner_in_lds;
       const GNLaunchPlan &pl = few ? lv.plan_few : lv.plan;
       a.n_lds = pl.owner_in_lds ? 0 : pl.owner_lds_entries;
-      a.handover = e->d_handover + (size_t)l * pair_layout(n_pairs).handover_stride;
-      int *second_heads = e->d_work_counters + (PHOVO_MAX_LEVELS + l) * QUEUES_PER_LEVEL;
+      const size_t hstride = pair_layout(n_pairs).handover_stride;
+      int *list0 = e->d_handover + (size_t)(2 * l) * hstride, *list1 = list0 + hstride;
+      int *heads1 = e->d_work_counters + (PHOVO_MAX_LEVELS + l) * QUEUES_PER_LEVEL;
+      int *heads2 = e->d_work_counters + (2 * PHOVO_MAX_LEVELS + l) * QUEUES_PER_LEVEL;
       if (!pl.owner_in_lds && e->slide_policy >= 0) {
         // Owner map too large for LDS: the sliding-window kernel first (owner ring in LDS); pairs whose warp leaves its
         // window are put on the hand-over list and continued, from the iteration they had reached, by the exact kernel
         // right behind it, which draws from that list.
-        a.handover_mode = HANDOVER_APPEND;
+        a.handover_out = list0;
         PHOVO_HIP_CHECK(gn_launch_level_slide(a, e->ext.plane_storage, e->cu_count, e->stream));
-        a.handover_mode = HANDOVER_TAKE; a.takeover_flag = PHOVO_PAIR_WINDOW_FALLBACK;
-        a.work_counter = second_heads; a.n_queues = 1;
+        a.handover_out = nullptr; a.handover_in = list0; a.takeover_flag = PHOVO_PAIR_WINDOW_FALLBACK;
+        a.work_counter = heads1; a.n_queues = 1;
       } else if (e->iter_cap > 0 && a.min_grad_norm > 0.0 && a.max_iter > e->iter_cap && !few) {
         // Data-dependent termination: most pairs stop after a few iterations, a few run to max_num_iterations, and
         // whichever of those a workgroup draws late finishes alone on its CU long after the queue is empty (the launch
         // then ends with one pair per CU at that CU's own fp64 rate).  So the first launch caps every pair at iter_cap
-        // iterations and hands the unfinished ones over; the second launch starts all of them at once, each from its
-        // stored state and iteration count, in the geometry that runs one pair fastest.  Every batch the persistent
-        // kernel takes in its throughput geometry goes this way, whatever its size, so that a pair's result does not
-        // depend on how many other pairs were aligned with it (a sequence gives the same trajectory file, byte for
-        // byte, on 1, 2 or 3 ranks: tests/test_sequence_sharded.py).
-        a.handover_mode = HANDOVER_APPEND; a.iter_cap = e->iter_cap;
+        // iterations and hands the unfinished ones over; the second starts all of them at once, each from its stored
+        // state and iteration count, in the geometry that runs one pair fastest, and (where max_num_iterations allows)
+        // caps them again at 3 x iter_cap for a third launch -- pairs of one launch then need about the same number
+        // of iterations and finish together.  Every batch the persistent kernel takes in its throughput geometry goes
+        // this way, whatever its size, so that a pair's result does not depend on how many other pairs were aligned with
+        // it (a sequence gives the same trajectory file, byte for byte, on 1, 2 or 3 ranks: tests/test_sequence_sharded.py).
+        a.handover_out = list0; a.iter_cap = e->iter_cap;
         PHOVO_HIP_CHECK(gn_launch_level(a, pl, e->ext.plane_storage, e->cu_count, e->stream));
-        a.handover_mode = HANDOVER_TAKE; a.iter_cap = 0; a.takeover_flag = 0;
-        a.work_counter = second_heads; a.n_queues = 1;
-        // the pairs that are left each need many iterations: the geometry that runs ONE pair fastest
-        if (!e->tail_same_plan && lv.plan_tail_ok && lv.plan_tail.owner_in_lds) {
-          PHOVO_HIP_CHECK(gn_launch_level(a, lv.plan_tail, e->ext.plane_storage, e->cu_count, e->stream));
-          PHOVO_HIP_CHECK(hipEventRecord(e->ev_stop[l], e->stream));
-          e->level_launched[l] = true;
-          continue;
+        const GNLaunchPlan &tail = (!e->tail_same_plan && lv.plan_tail_ok && lv.plan_tail.owner_in_lds) ? lv.plan_tail : pl;
+        a.takeover_flag = 0; a.n_queues = 1;
+        const int cap2 = 3 * e->iter_cap;
+        // (a third launch pays on the larger levels: 160x120, 8192 pairs 3.85 -> 3.63 ms; on 80x60 its fixed cost is
+        // larger than what the better balance returns)
+        if (e->tail_stages >= 3 && a.max_iter > cap2 && lv.n >= 16384) {
+          a.handover_in = list0; a.handover_out = list1; a.iter_cap = cap2; a.work_counter = heads1;
+          PHOVO_HIP_CHECK(gn_launch_level(a, tail, e->ext.plane_storage, e->cu_count, e->stream));
+          a.handover_in = list1; a.work_counter = heads2;
+        } else {
+          a.handover_in = list0; a.work_counter = heads1;
         }
+        a.handover_out = nullptr; a.iter_cap = 0;
+        PHOVO_HIP_CHECK(gn_launch_level(a, tail, e->ext.plane_storage, e->cu_count, e->stream));
+        PHOVO_HIP_CHECK(hipEventRecord(e->ev_stop[l], e->stream));
+        e->level_launched[l] = true;
+        continue;
       }
       PHOVO_HIP_CHECK(gn_launch_level(a, pl, e->ext.plane_storage, e->cu_count, e->stream));
       if (!pl.owner_in_lds) e->owner_tagged = true;          // tagged entries stay behind (the kernel wipes per pair)

@@ -246,23 +246,23 @@ __device__ __forceinline__ int draw_pair(int *heads, int n_queues, int n_pairs)
   return n_pairs;
 }
 
-// Next pair for the calling workgroup in any hand-over mode (GNLevelArgs): HANDOVER_TAKE draws an index into the list the
-// previous launch of the level left behind (length at handover[n_pairs], final since that launch has ended) and returns
-// the pair stored there; otherwise the plain queue.  n_pairs = nothing left.
+// Next pair for the calling workgroup: with GNLevelArgs::handover_in an index into the list an earlier launch of the level
+// left behind (length at [n_pairs], final since that launch has ended) and the pair stored there; otherwise the plain
+// queue.  n_pairs = nothing left.
 __device__ __forceinline__ int draw_pair_any(const GNLevelArgs &A)
 {
-  if (A.handover_mode != HANDOVER_TAKE) return draw_pair(A.work_counter, A.n_queues, A.n_pairs);
-  const int count = __hip_atomic_load(&A.handover[A.n_pairs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (!A.handover_in) return draw_pair(A.work_counter, A.n_queues, A.n_pairs);
+  const int count = __hip_atomic_load(&A.handover_in[A.n_pairs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int i = atomicAdd(A.work_counter, 1);
-  return i < count ? __hip_atomic_load(&A.handover[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : A.n_pairs;
+  return i < count ? __hip_atomic_load(&A.handover_in[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : A.n_pairs;
 }
 
-// HANDOVER_APPEND: the calling thread puts `pair` on the list (after its state and iteration count have been stored; the
-// kernel boundary makes all of it visible to the next launch).
+// The calling thread puts `pair` on handover_out (after its state and iteration count have been stored; the kernel
+// boundary makes all of it visible to the next launch).
 __device__ __forceinline__ void handover_append(const GNLevelArgs &A, int pair)
 {
-  const int slot = atomicAdd(&A.handover[A.n_pairs], 1);
-  A.handover[slot] = pair;
+  const int slot = atomicAdd(&A.handover_out[A.n_pairs], 1);
+  A.handover_out[slot] = pair;
 }
 
 // v_writelane_b32: lane `lane` (wave-uniform) of `old` becomes `value` (wave-uniform); the other lanes keep theirs.

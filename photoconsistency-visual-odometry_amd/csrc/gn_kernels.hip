@@ -75,7 +75,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
   // the iteration loop and the barrier at the head of the work loop is one if-block (two adjacent `if (tid == 0)`
   // blocks, one either side of the back edge, were threaded together by the compiler into a loop that reached that
   // barrier with thread 0 parked: a hang).
-  // (draw_pair_any: in HANDOVER_TAKE mode the pairs come from the list an earlier launch of this level left behind)
+  // (draw_pair_any: with handover_in the pairs come from the list an earlier launch of this level left behind)
   if (tid == 0) s_ctl[CTL_PAIR] = draw_pair_any(A);
   for (;;) {
   // The ticket thread 0 has just stored must have LEFT its LDS queue before any wave is released: the compiler omits
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
   const double cd0 = (double)c0, rd0 = (double)r0;
 
   int iteration = 0;                // continuing a pair an earlier launch handed over: its completed iterations count
-  if (A.handover_mode == HANDOVER_TAKE) iteration = __builtin_amdgcn_readfirstlane(A.reports[pair].iterations[A.level]);
+  if (A.handover_in) iteration = __builtin_amdgcn_readfirstlane(A.reports[pair].iterations[A.level]);
   bool handed_over = false;
   double last_gnorm = 0.0;
 #ifdef PHOVO_STAMPS
@@ -482,9 +482,9 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
       if (it >= A.max_iter) done = true;                                                // :383
       else if (gnorm < A.min_grad_norm) done = true;                                    // :388
       if (!finite) done = true;     // the reference would keep iterating on NaN; the result is the same NaN
-      // HANDOVER_APPEND with a cap: a pair still running after iter_cap iterations leaves this launch here (state and
-      // pose constants are stored as for any other iteration) and is continued by the next launch of the level
-      const bool hand = !done && A.handover_mode == HANDOVER_APPEND && A.iter_cap > 0 && it >= A.iter_cap;
+      // handover_out with a cap: a pair still running once it has done iter_cap iterations of the level leaves this
+      // launch here (its state is stored as after any other iteration) and is continued by the next launch of the level
+      const bool hand = !done && A.handover_out != nullptr && A.iter_cap > 0 && it >= A.iter_cap;
       PHOVO_SUBSTAMP(1)
       if (!done) write_pose_constants(st[0], st[1], st[2], st[3], st[4], st[5], s_cst, lane);   // wave-uniform branch
       PHOVO_SUBSTAMP(2)
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
       A.reports[pair].iterations[A.level] = iteration;
       A.reports[pair].gradient_norm = last_gnorm;
       A.reports[pair].flags |= (uint32_t)s_ctl[CTL_FLAGS];
-      if (A.handover_mode == HANDOVER_TAKE) A.reports[pair].flags |= A.takeover_flag;
+      if (A.handover_in) A.reports[pair].flags |= A.takeover_flag;
 #ifdef PHOVO_STAMPS
       // diagnostic build only: phase cycle sums of wave 0 go to the otherwise unused report slots 8..12
       for (int j = 0; j < 5; j++) A.reports[pair].iterations[8 + j] = (int)(st_sum[j] / (unsigned long long)iteration);

@@ -16,7 +16,7 @@
 //     are gathered, a whole phase before pass 2 needs them -- and band s - 8 is consumed by pass 2.  Rotations and
 //     translations of the sizes Gauss-Newton steps take move a pixel by a few rows; 6 bands are 38 rows at 320 px width.
 //   * a source pixel whose target falls OUTSIDE the window sets a flag.  The iteration is then void: the state is left
-//     as it was, the pair is put on GNLevelArgs::handover and the engine's follow-up launch of gn_level_kernel (HBM
+//     as it was, the pair is put on GNLevelArgs::handover_out and the engine's follow-up launch of gn_level_kernel (HBM
 //     owner map, exact for any motion) continues that pair from the same iteration.  Results are therefore exactly
 //     the reference's whatever the motion; only the speed depends on the window.
 //
@@ -436,7 +436,7 @@ static hipError_t launch_slide_geom(const GNLevelArgs &a, int storage, int n_blo
 hipError_t gn_launch_level_slide(const GNLevelArgs &a, int storage, int cu_count, hipStream_t stream)
 {
   if (a.n_pairs <= 0) return hipSuccess;
-  if (!a.handover || a.handover_mode != HANDOVER_APPEND) return hipErrorInvalidValue;
+  if (!a.handover_out || a.handover_in) return hipErrorInvalidValue;
   const int n_blocks = a.n_pairs < cu_count ? a.n_pairs : cu_count;     // persistent grid, one workgroup per CU
   return launch_slide_geom<PHOVO_SLIDE_GEOM>(a, storage, n_blocks, stream);
 }

@@ -37,22 +37,22 @@ struct GNLevelArgs {
   int *work_counter;        // [QUEUES_PER_LEVEL] heads, zeroed before the launch: workgroups draw pair indices from them
   int n_queues;             // 1: one queue for the whole grid; 8: one per XCD over a contiguous eighth of the pairs (+ stealing)
   int n_lds;                // owner map in HBM only: its first n_lds entries (a multiple of 64) live in LDS instead
-  // Hand-over of unfinished pairs from one launch of a level to the next (both on the same stream):
-  //   handover      [n_pairs + 1] ints, zeroed before the first launch: a compact list of pair indices, [n_pairs] = its length
-  //   handover_mode HANDOVER_NONE; HANDOVER_APPEND: a pair this launch does not finish is appended (its state and its
-  //                 completed iteration count, reports[p].iterations[level], are in place); HANDOVER_TAKE: the launch works
-  //                 on the list instead of the pairs 0..n_pairs-1 and continues every pair at that iteration count
-  //   iter_cap      HANDOVER_APPEND only, > 0: a pair that has not terminated after iter_cap iterations is handed over
-  //                 (0: no cap -- the sliding-window kernel hands over for its own reason)
-  //   takeover_flag HANDOVER_TAKE only: OR-ed into reports[p].flags of every pair taken (PHOVO_PAIR_WINDOW_FALLBACK or 0)
-  int *handover;
-  int handover_mode;
+  // Hand-over of unfinished pairs from one launch of a level to the next (all on the same stream).  A list is
+  // [n_pairs + 1] ints, zeroed before the first launch: pair indices, and at [n_pairs] their number.
+  //   handover_out  non-null: a pair this launch does not finish is appended there (its state and its completed iteration
+  //                 count, reports[p].iterations[level], are in place)
+  //   iter_cap      with handover_out, > 0: a pair that has not terminated once it has done iter_cap iterations of the
+  //                 level is handed over (0: no cap -- the sliding-window kernel hands over for its own reason)
+  //   handover_in   non-null: the launch works on that list instead of the pairs 0..n_pairs-1 and continues every pair at
+  //                 its stored iteration count; takeover_flag is OR-ed into reports[p].flags of every pair taken
+  //                 (PHOVO_PAIR_WINDOW_FALLBACK or 0)
+  const int *handover_in;
+  int *handover_out;
   int iter_cap;
   unsigned takeover_flag;
 };
 
 constexpr int QUEUES_PER_LEVEL = 8;      // one per XCD
-enum { HANDOVER_NONE = 0, HANDOVER_APPEND = 1, HANDOVER_TAKE = 2 };
 
 struct GNLaunchPlan {
   int variant;              // which instantiation of the level kernel (gn_kernels.hip)
@@ -83,7 +83,7 @@ hipError_t gn_run_level_wide(const GNLevelArgs &args, int n_pairs, void *workspa
                              hipStream_t stream);
 hipError_t gn_prepare_kernels();   // raises the dynamic-LDS limit of every instantiation
 // Sliding-window form for levels whose owner map exceeds LDS (gn_slide_kernel.hip): owner ring in LDS; pairs whose
-// motion leaves the window are appended to args.handover for a follow-up gn_launch_level in HANDOVER_TAKE mode.
+// motion leaves the window are appended to args.handover_out for a follow-up gn_launch_level that takes that list.
 hipError_t gn_prepare_slide_kernels();
 hipError_t gn_launch_level_slide(const GNLevelArgs &args, int storage, int cu_count, hipStream_t stream);
 size_t gn_slide_lds_bytes();
