@@ -1,7 +1,7 @@
 // PhotoconsistencyVisualOdometry on the MI355X path: frame-to-frame odometry over a TUM-format RGB-D
 // directory, writing a TUM trajectory file.
 //
-//   ./PhotoconsistencyVisualOdometry <config_file.yml> <rgbd_dataset_directory> <output_trajectory_file> [--batch]
+//   ./PhotoconsistencyVisualOdometry <config_file.yml> <rgbd_dataset_directory> <output_trajectory_file> [--batch [--gpus N]]
 //
 // Behaviour kept from the reference's app (apps/PhotoconsistencyVisualOdometry/PhotoconsistencyVisualOdometry.cpp):
 //   * <dir>/rgb.txt and <dir>/depth.txt are read in lock step -- line n of one is paired with line n of the
@@ -14,7 +14,9 @@
 // Default mode goes pair by pair through the class surface exactly like the reference's loop and prints
 // `Time = ... sec.` and `Rt:` for each.  --batch loads the whole sequence, builds every pyramid once on the
 // GPU (the reference builds each frame's pyramids twice, :222-223) and aligns all pairs in one batched call;
-// the trajectory is identical.
+// the trajectory is identical.  --batch --gpus N cuts the pairs into N contiguous ranges, one engine and one host thread
+// per device (single process: the results meet in host memory, no collective); the trajectory file is the same for
+// every N.  The one-process-per-GPU form with the RCCL all_gather is apps/PhotoconsistencyVisualOdometrySharded.py.
 #include <sys/stat.h>
 
 #include <algorithm>
@@ -98,7 +100,7 @@ static bool writePose(std::ofstream &f, double timestamp, const Matrix44Type &po
 static void printHelp()
 {
   std::cout << "./PhotoconsistencyVisualOdometry <config_file.yml> <rgbd_dataset_directory> "
-               "<output_trajectory_file> [--batch]" << std::endl;
+               "<output_trajectory_file> [--batch [--gpus N]]" << std::endl;
 }
 
 #define PHOVO_OK_OR_FAIL(call)                                                              \
@@ -108,7 +110,15 @@ int main(int argc, char *argv[])
 {
   if (argc < 4) { printHelp(); return EXIT_FAILURE; }
   const std::string configFile(argv[1]), datasetDir(argv[2]), trajectoryPath(argv[3]);
-  const bool batch = argc > 4 && std::string(argv[4]) == "--batch";
+  bool batch = false;
+  int nGpus = 1;                                      // --batch --gpus N: the pairs of the sequence sharded over N devices
+  for (int i = 4; i < argc; i++) {
+    const std::string a(argv[i]);
+    if (a == "--batch") batch = true;
+    else if (a == "--gpus" && i + 1 < argc) nGpus = std::atoi(argv[++i]);
+    else { printHelp(); return EXIT_FAILURE; }
+  }
+  if (nGpus < 1 || (nGpus > 1 && !batch)) { std::cerr << "--gpus N needs --batch and N >= 1" << std::endl; return EXIT_FAILURE; }
   if (!fileExists(configFile)) { std::cerr << "Input config file " << configFile << " does not exist" << std::endl; return EXIT_FAILURE; }
   if (!fileExists(datasetDir)) { std::cerr << "Input RGBD dataset directory " << datasetDir << " does not exist" << std::endl; return EXIT_FAILURE; }
   const std::string rgbList = datasetDir + "/rgb.txt", depthList = datasetDir + "/depth.txt";
@@ -172,12 +182,13 @@ int main(int argc, char *argv[])
     } else {
       phovo_config cfg;
       PHOVO_OK_OR_FAIL(phovo_config_read_file(configFile.c_str(), &cfg));
-      phovo_engine *engine = nullptr;
-      PHOVO_OK_OR_FAIL(phovo_engine_create(0, &engine));
-      PHOVO_OK_OR_FAIL(phovo_engine_set_config(engine, &cfg));
-      PHOVO_OK_OR_FAIL(phovo_engine_set_intrinsic_matrix(engine, intrinsicMatrix.data()));
-      // Frames are decoded into two packed host arrays and handed over in one batched call: one copy and one
-      // producer launch per pyramid level for every 32 frames.
+      const int nDevices = phovo_device_count();
+      if (nDevices < 1) { std::cerr << "phovo_engine_create: no HIP device available: this library has no CPU path" << std::endl; return EXIT_FAILURE; }
+      // PHOVO_VO_SHARE_DEVICES=1 lets more shards than devices run (a rehearsal of --gpus N on a smaller machine)
+      if (nGpus > nDevices && !std::getenv("PHOVO_VO_SHARE_DEVICES")) {
+        std::cerr << "--gpus " << nGpus << " but only " << nDevices << " device(s) are visible" << std::endl;
+        return EXIT_FAILURE;
+      }
       // Decoding is the bulk of this mode's wall time (a 640x480 colour PNG + its 16-bit depth PNG take 6-20 ms on one
       // core, the alignment of the whole sequence a few milliseconds on the GPU): frames are independent, so they
       // are decoded by all host threads at once, each straight into its slot of the two packed arrays.
@@ -225,18 +236,46 @@ int main(int argc, char *argv[])
           return EXIT_FAILURE;
         }
       }
-      PHOVO_OK_OR_FAIL(phovo_engine_reserve_frames(engine, (int)nFrames, W, H));
-      PHOVO_OK_OR_FAIL(phovo_engine_upload_frames_u16(engine, 0, (int)nFrames, PHOVO_ROLE_BOTH, allGray.data(), (size_t)W,
-                                                      (size_t)W * H, allDepth.data(), sizeof(uint16_t) * (size_t)W,
-                                                      sizeof(uint16_t) * (size_t)W * H, depthScalingFactor));
+      // Pair t aligns frame t with frame t+1 and depends on nothing else (:175,222-224): the pairs are cut into nGpus
+      // contiguous ranges (the first nPairs % nGpus ranges one pair longer), each range gets its own engine on its own
+      // device and its own host thread, and needs the frames of its range plus one.  In ONE process the results meet
+      // in host memory: no collective (the multi-process form, PhotoconsistencyVisualOdometrySharded.py, is where the
+      // RCCL all_gather is).  A pair's result does not depend on its batch, so the file is the same for every N.
       const int nPairs = (int)nFrames - 1;
-      std::vector<int> src(nPairs), tgt(nPairs);
-      for (int p = 0; p < nPairs; p++) { src[p] = p; tgt[p] = p + 1; }
       std::vector<double> states((size_t)nPairs * 6);
+      std::vector<std::string> shardError(nGpus);
       const auto t0 = std::chrono::steady_clock::now();
-      PHOVO_OK_OR_FAIL(phovo_engine_align_pairs(engine, nPairs, src.data(), tgt.data(), nullptr, states.data(), nullptr));
+      auto alignShard = [&](int g) {
+        const int base = nPairs / nGpus, extra = nPairs % nGpus;
+        const int a = g * base + (g < extra ? g : extra), b = a + base + (g < extra ? 1 : 0);
+        if (b <= a) return;
+        const int f0 = a, nf = b - a + 1;
+        phovo_engine *engine = nullptr;
+        auto fail = [&](const char *what) { shardError[g] = std::string(what) + ": " + phovo_last_error(); if (engine) phovo_engine_destroy(engine); };
+        if (phovo_engine_create(g % nDevices, &engine) != PHOVO_OK) return fail("phovo_engine_create");
+        if (phovo_engine_set_config(engine, &cfg) != PHOVO_OK) return fail("phovo_engine_set_config");
+        if (phovo_engine_set_intrinsic_matrix(engine, intrinsicMatrix.data()) != PHOVO_OK) return fail("phovo_engine_set_intrinsic_matrix");
+        if (phovo_engine_reserve_frames(engine, nf, W, H) != PHOVO_OK) return fail("phovo_engine_reserve_frames");
+        if (phovo_engine_upload_frames_u16(engine, 0, nf, PHOVO_ROLE_BOTH, allGray.data() + (size_t)W * H * f0, (size_t)W,
+                                           (size_t)W * H, allDepth.data() + (size_t)W * H * f0, sizeof(uint16_t) * (size_t)W,
+                                           sizeof(uint16_t) * (size_t)W * H, depthScalingFactor) != PHOVO_OK)
+          return fail("phovo_engine_upload_frames_u16");
+        std::vector<int> src(b - a), tgt(b - a);
+        for (int p = 0; p < b - a; p++) { src[p] = p; tgt[p] = p + 1; }
+        if (phovo_engine_align_pairs(engine, b - a, src.data(), tgt.data(), nullptr, states.data() + (size_t)a * 6, nullptr) != PHOVO_OK)
+          return fail("phovo_engine_align_pairs");
+        phovo_engine_destroy(engine);
+      };
+      {
+        std::vector<std::thread> shards;
+        for (int g = 1; g < nGpus; g++) shards.emplace_back(alignShard, g);
+        alignShard(0);
+        for (auto &th : shards) th.join();
+      }
+      for (const auto &e : shardError) if (!e.empty()) { std::cerr << e << std::endl; return EXIT_FAILURE; }
       const auto t1 = std::chrono::steady_clock::now();
-      std::cout << "Time = " << std::chrono::duration<double>(t1 - t0).count() << " sec. (" << nPairs << " pairs)" << std::endl;
+      std::cout << "Time = " << std::chrono::duration<double>(t1 - t0).count() << " sec. (" << nPairs << " pairs on " << nGpus
+                << " device(s), upload and pyramids included)" << std::endl;
       std::vector<double> poses((size_t)nPairs * 16);
       PHOVO_OK_OR_FAIL(phovo_trajectory_chain(nPairs, states.data(), pose.data(), poses.data()));
       for (int p = 0; p < nPairs; p++) {
@@ -244,7 +283,6 @@ int main(int argc, char *argv[])
         for (int i = 0; i < 16; i++) P(i) = poses[(size_t)p * 16 + i];
         if (!writePose(trajectoryFile, rgb[(size_t)p + 1].timestamp, P)) return EXIT_FAILURE;
       }
-      phovo_engine_destroy(engine);
     }
   } catch (const std::exception &e) {
     std::cerr << "error: " << e.what() << std::endl;

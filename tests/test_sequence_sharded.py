@@ -175,6 +175,19 @@ def test_sharded_sequence_is_byte_identical_to_the_single_process_app(tmp_path):
         assert out.read_bytes() == want, ranks
         if ranks == 3:
             assert "rank 2/3 decoded frames [400, 601) for pairs [400, 600)" in r.stderr
+    # the C++ app's own multi-device mode (threads, one engine per device, no collective): same bytes for every N; on this
+    # one-GPU box the shards share the device (PHOVO_VO_SHARE_DEVICES=1), without that switch N > devices is refused
+    for n in (2, 3):
+        out = tmp_path / f"threads_{n}.txt"
+        r = subprocess.run([APP, CFG5, str(seq), str(out), "--batch", "--gpus", str(n)], capture_output=True, text=True,
+                           timeout=900, env=_clean_env({"PHOVO_VO_SHARE_DEVICES": "1"}))
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert out.read_bytes() == want, n
+        assert f"on {n} device(s)" in r.stdout
+    if native.lib().phovo_device_count() < 2:
+        r = subprocess.run([APP, CFG5, str(seq), str(tmp_path / "refused.txt"), "--batch", "--gpus", "2"],
+                           capture_output=True, text=True, timeout=900, env=_clean_env())
+        assert r.returncode != 0 and "device(s) are visible" in r.stderr
     # the poses are real: consecutive frames of the generator are a few centimetres apart
     last = [float(v) for v in want.decode().strip().split("\n")[-1].split()]
     assert np.isfinite(last).all() and abs(np.linalg.norm(last[4:8]) - 1.0) < 1e-9
