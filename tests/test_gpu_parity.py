@@ -795,24 +795,24 @@ def test_iteration_cap_hand_over_leaves_results_unchanged(monkeypatch):
 
 
 def test_randomised_sweep_against_oracle():
-    """tools/fuzz_parity.py: 80 random problems (odd sizes, 1-3 levels, perturbed intrinsics, NaN / negative /
+    """tests/tools/fuzz_parity.py: 80 random problems (odd sizes, 1-3 levels, perturbed intrinsics, NaN / negative /
     out-of-range depth, large motions, non-zero initial states, 1 / 3 / 40 pairs), each held to the 1e-9 pose bar and
     to identical iteration counts.  Longer sweeps of the same tool (1500 cases) are quoted in DESIGN.md section 4."""
     import subprocess
     import sys
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "80", "7"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "fuzz_parity.py"), "80", "7"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "80 cases, 0 failures" in r.stdout
 
 
 def test_randomised_sweep_of_large_levels_against_oracle():
-    """tools/fuzz_parity.py in its `big` mode: 40 random problems of 240x200 ... 700x500 pixels with 1-2 levels, 40 or 300
+    """tests/tools/fuzz_parity.py in its `big` mode: 40 random problems of 240x200 ... 700x500 pixels with 1-2 levels, 40 or 300
     pairs, in-plane rotations of up to 0.25 rad -- level 0 exceeds what an owner map in LDS holds, so this sweeps the
     sliding-window kernel and (for the large rotations) its hand-over to the exact kernel; same bars."""
     import subprocess
     import sys
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "40", "11", "big"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "fuzz_parity.py"), "40", "11", "big"],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "40 cases, 0 failures" in r.stdout

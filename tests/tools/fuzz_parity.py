@@ -3,7 +3,7 @@ half-integers, depth holes / NaN / out-of-range depth, large motions, non-zero i
 the sizes select, optionally narrow storage / Huber / bilinear.  Prints one line per failure and a summary; exit code 1
 if any case misses the 1e-9 pose bar or an iteration count.
 
-    python tools/fuzz_parity.py [cases=150] [seed=0] [ext] [big]
+    python tests/tools/fuzz_parity.py [cases=150] [seed=0] [ext] [big]
 
 With `ext` every case also draws a combination of the opt-in extensions (fp32 / fp16 plane storage, Huber weights,
 bilinear sampling with or without the corrected Jacobian); the oracle is then fed the planes as the device stored them.
@@ -16,7 +16,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import phovo_amd  # noqa: E402,F401
 from phovo_amd import native, odometry, se3, synthetic  # noqa: E402
 from oracle import oracle  # noqa: E402

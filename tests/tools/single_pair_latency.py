@@ -6,12 +6,12 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import phovo_amd  # noqa: E402,F401
 from phovo_amd import native, odometry, synthetic  # noqa: E402
 from oracle import oracle  # noqa: E402
 
-CFG = os.path.join(os.path.dirname(__file__), "..", "config_files")
+CFG = os.path.join(os.path.dirname(__file__), "..", "..", "config_files")
 for yml, size in (("config_4_level_optimization_analytic.yml", (640, 480)),
                   ("config_5_level_optimization_analytic.yml", (640, 480)),
                   ("config_6_level_optimization_analytic.yml", (1280, 960)),
