@@ -65,3 +65,28 @@ def test_parent_touches_nothing_gpu_side_before_launching():
     src = ast.get_source_segment(open(BENCH).read(), lr)
     assert "os.exec" not in src and "execv" not in src          # children, never a replaced process
     assert "Popen" in src
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_two_gloo_ranks_share_the_gpu_and_print_one_contract_line():
+    """`python bench.py --gpus 2` with no launcher around it, on a one-GPU box (gloo instead of RCCL, which refuses two
+    ranks on one device): the parent starts both ranks, each aligns its own shard on the shared card, one all_gather per
+    step, rank 0 prints ONE JSON line with the driver's contract keys; value = pairs of both ranks / slowest rank's time."""
+    import json
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--pairs", "256", "--distinct", "8", "--no-cpu-baseline"],
+             {"PHOVO_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["dtype"] == "f64"
+    assert d["config"]["pairs_per_gpu"] == 256 and d["config"]["global_pairs_per_step"] == 512
+    assert d["value"] > 0 and d["nonfinite_pairs"] == 0 and d["cpu_baseline"] is None
+    assert abs(d["value"] - 512 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    assert "rank 0/2 joined the gloo group" in r.stderr and "rank 1/2 joined the gloo group" in r.stderr
