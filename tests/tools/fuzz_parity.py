@@ -110,6 +110,8 @@ for case in range(cases):
         print(f"FAIL case {case}: {w}x{h} levels {nl} max_iter {max_iter} min_grad {min_grad} pairs {n_pairs} "
               f"iterations gpu {its} cpu {eits} distance {d:.3e} flags {reps[0].flags} "
               f"ext(storage {storage}, huber {huber}, bilinear {bilinear}, corrected {corrected})")
+    if (case + 1) % 500 == 0:                 # a long sweep must not look hung to whoever is watching its output
+        print(f"... {case + 1} cases so far, {bad} failures, worst {worst:.3e}", flush=True)
 print(f"{cases} cases, {bad} failures, worst pose distance {worst:.3e}")
 print(f"pairs finished by the exact kernel after leaving the sliding window: {fallbacks} cases")
 print("launch geometries exercised (threads, owner in LDS, source in LDS, wide form): ", variants)
