@@ -217,6 +217,12 @@ int phovo_engine_set_iteration_cap(phovo_engine *e, int cap);
 /* 1 if `level` would run in the wide form for a batch of n_pairs under the current settings. */
 int phovo_engine_level_uses_wide(const phovo_engine *e, int level, int n_pairs);
 
+/* Page-locks (and releases) a host buffer the caller will hand to the upload entry points repeatedly: uploads from
+ * registered memory are direct DMA at the link rate instead of going through the runtime's bounce buffers.  Optional;
+ * plain hipHostRegister / hipHostUnregister behind the C ABI for hosts that do not link the HIP runtime themselves. */
+int phovo_host_register(void *ptr, size_t bytes);
+int phovo_host_unregister(void *ptr);
+
 /* (Re)allocates the frame pool: n_frames frames of width x height.  Uses the current config. */
 int phovo_engine_reserve_frames(phovo_engine *e, int n_frames, int width, int height);
 int phovo_engine_level_size(const phovo_engine *e, int level, int *width, int *height);

@@ -50,6 +50,8 @@ using namespace phovo_hip;
 struct phovo_engine {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;           // batched uploads: host-to-device copies of chunk i+1 run beside the pyramid kernels of chunk i
+  hipEvent_t ev_copied[2] = {}, ev_built[2] = {};     // per staging half
   hipEvent_t ev_start[PHOVO_MAX_LEVELS] = {};
   hipEvent_t ev_stop[PHOVO_MAX_LEVELS] = {};
   bool level_launched[PHOVO_MAX_LEVELS] = {};
@@ -239,17 +241,22 @@ int ensure_stage(phovo_engine *e, int frames, bool want_f64, bool want_u16)
 
 // Builds the pyramids of `count` consecutive frames whose raw data sits in the staging buffers:
 // one launch per (level, producer) for the whole batch.
-int build_pyramids(phovo_engine *e, int first_frame, int count, int roles, DepthKind kind, double depth_scale)
+int build_pyramids(phovo_engine *e, int first_frame, int count, int roles, DepthKind kind, double depth_scale,
+                   int stage_offset = 0)
 {
   const int w = e->width, h = e->height;
   const size_t px = (size_t)w * (size_t)h;
+  // the raw frames of this chunk sit `stage_offset` frames into the staging buffers (double-buffered uploads)
+  const uint8_t *s_gray = e->d_gray + px * (size_t)stage_offset;
+  const double *s_depth = e->d_depth ? e->d_depth + px * (size_t)stage_offset : nullptr;
+  const uint16_t *s_depth16 = e->d_depth16 ? e->d_depth16 + px * (size_t)stage_offset : nullptr;
   const int storage = e->ext.plane_storage;
   // blurFilterSize[0] > 0: the converted level-0 image, blurred twice, is the image every other level is resized from
   // (whether or not level 0 itself is resident)
   const double *blurred0 = nullptr;
   if (e->cfg.blur_filter_size[0] > 0) {
     const int ks0 = e->cfg.blur_filter_size[0];
-    PHOVO_HIP_CHECK(pyr_intensity_level(e->d_gray, px, count, w, h, 0, w, h, e->d_blur0, px, e->stream));   // convertTo  :471,484
+    PHOVO_HIP_CHECK(pyr_intensity_level(s_gray, px, count, w, h, 0, w, h, e->d_blur0, px, e->stream));   // convertTo  :471,484
     for (int f = 0; f < count; f++) {
       PHOVO_HIP_CHECK(pyr_gaussian_blur(e->d_blur0 + (size_t)f * px, e->d_tmp, w, h, ks0, e->d_blur_kernel, e->stream));
       PHOVO_HIP_CHECK(pyr_gaussian_blur(e->d_blur0 + (size_t)f * px, e->d_tmp, w, h, ks0, e->d_blur_kernel, e->stream));
@@ -275,7 +282,7 @@ int build_pyramids(phovo_engine *e, int first_frame, int count, int roles, Depth
       PHOVO_HIP_CHECK(pyr_depth_level(blurred0, px, count, w, h, l, lv.w, lv.h, base + (size_t)PLANE_I * lv.n, fstride,
                                       e->stream));
     } else {
-      PHOVO_HIP_CHECK(pyr_intensity_level(e->d_gray, px, count, w, h, l, lv.w, lv.h,
+      PHOVO_HIP_CHECK(pyr_intensity_level(s_gray, px, count, w, h, l, lv.w, lv.h,
                                           base + (size_t)PLANE_I * lv.n, fstride, e->stream));
     }
     if (ks > 0 && !(blurred0 && l == 0)) {                              // GaussianBlur twice  :144-148
@@ -288,9 +295,9 @@ int build_pyramids(phovo_engine *e, int first_frame, int count, int roles, Depth
     if (roles & PHOVO_ROLE_SOURCE) {                                    // BuildPyramid(depth, false)  :475
       double *pd = base + (size_t)PLANE_D * lv.n;
       if (kind == DEPTH_U16)
-        PHOVO_HIP_CHECK(pyr_depth_level_u16(e->d_depth16, px, depth_scale, count, w, h, l, lv.w, lv.h, pd, fstride, e->stream));
+        PHOVO_HIP_CHECK(pyr_depth_level_u16(s_depth16, px, depth_scale, count, w, h, l, lv.w, lv.h, pd, fstride, e->stream));
       else
-        PHOVO_HIP_CHECK(pyr_depth_level(e->d_depth, px, count, w, h, l, lv.w, lv.h, pd, fstride, e->stream));
+        PHOVO_HIP_CHECK(pyr_depth_level(s_depth, px, count, w, h, l, lv.w, lv.h, pd, fstride, e->stream));
     }
     if (roles & PHOVO_ROLE_TARGET)                                      // BuildDerivativesPyramids  :490
       PHOVO_HIP_CHECK(pyr_scharr(base, fstride, (size_t)PLANE_I * lv.n, (size_t)PLANE_GX * lv.n,
@@ -412,6 +419,11 @@ int phovo_engine_create(int device, phovo_engine **out)
   phovo_config_default(&e->cfg);
   phovo_extensions_default(&e->ext);
   hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+  if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking);
+  for (int i = 0; i < 2 && he == hipSuccess; i++) {
+    he = hipEventCreateWithFlags(&e->ev_copied[i], hipEventDisableTiming);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_built[i], hipEventDisableTiming);
+  }
   if (he == hipSuccess) {
     for (int l = 0; l < PHOVO_MAX_LEVELS && he == hipSuccess; l++) {
       he = hipEventCreate(&e->ev_start[l]);
@@ -447,6 +459,11 @@ int phovo_engine_destroy(phovo_engine *e)
     if (e->ev_start[l]) (void)hipEventDestroy(e->ev_start[l]);
     if (e->ev_stop[l]) (void)hipEventDestroy(e->ev_stop[l]);
   }
+  for (int i = 0; i < 2; i++) {
+    if (e->ev_copied[i]) (void)hipEventDestroy(e->ev_copied[i]);
+    if (e->ev_built[i]) (void)hipEventDestroy(e->ev_built[i]);
+  }
+  if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return PHOVO_OK;
@@ -577,6 +594,20 @@ int phovo_engine_set_build_all_levels(phovo_engine *e, int on)
   return PHOVO_OK;
 }
 
+int phovo_host_register(void *ptr, size_t bytes)
+{
+  if (!ptr || bytes == 0) return fail(PHOVO_E_INVALID_ARGUMENT, "host_register: null or empty");
+  PHOVO_HIP_CHECK(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+  return PHOVO_OK;
+}
+
+int phovo_host_unregister(void *ptr)
+{
+  if (!ptr) return fail(PHOVO_E_INVALID_ARGUMENT, "host_unregister: null");
+  PHOVO_HIP_CHECK(hipHostUnregister(ptr));
+  return PHOVO_OK;
+}
+
 int phovo_engine_reserve_frames(phovo_engine *e, int n_frames, int width, int height)
 {
   if (!e) return fail(PHOVO_E_INVALID_ARGUMENT, "reserve_frames: null");
@@ -672,17 +703,17 @@ int phovo_engine_level_is_stored(const phovo_engine *e, int level)
 // Copies `count` frames (rows `stride` bytes apart, frames `frame_stride` bytes apart) into a packed
 // staging buffer.
 static int stage_frames_h2d(phovo_engine *e, void *dst, const void *src, size_t stride, size_t frame_stride,
-                            size_t elem, int count)
+                            size_t elem, int count, hipStream_t stream)
 {
   const size_t row = elem * (size_t)e->width, frame_bytes = row * (size_t)e->height;
   if (stride == row && (frame_stride == frame_bytes || count == 1)) {
-    PHOVO_HIP_CHECK(hipMemcpyAsync(dst, src, frame_bytes * (size_t)count, hipMemcpyHostToDevice, e->stream));
+    PHOVO_HIP_CHECK(hipMemcpyAsync(dst, src, frame_bytes * (size_t)count, hipMemcpyHostToDevice, stream));
     return PHOVO_OK;
   }
   for (int f = 0; f < count; f++) {
     const int st = copy_rows_to_device(static_cast<char *>(dst) + frame_bytes * (size_t)f,
                                        static_cast<const char *>(src) + frame_stride * (size_t)f, stride, row,
-                                       e->height, e->stream);
+                                       e->height, stream);
     if (st != PHOVO_OK) return st;
   }
   return PHOVO_OK;
@@ -702,24 +733,39 @@ static int upload_batch(phovo_engine *e, int first_frame, int count, int roles,
   if (count == 0) return PHOVO_OK;
   PHOVO_HIP_CHECK(hipSetDevice(e->device));
   const int chunk_cap = count < STAGE_CHUNK ? count : STAGE_CHUNK;
-  int st = ensure_stage(e, chunk_cap, kind == DEPTH_F64, kind == DEPTH_U16);
+  // Two staging halves: while the pyramid kernels of chunk i read one half on the engine's stream, chunk i + 1 is copied
+  // into the other on the copy stream (events order each half: copied -> built -> copied again).
+  const bool two_halves = count > chunk_cap;
+  int st = ensure_stage(e, two_halves ? 2 * chunk_cap : chunk_cap, kind == DEPTH_F64, kind == DEPTH_U16);
   if (st != PHOVO_OK) return st;
-  for (int done = 0; done < count; done += chunk_cap) {
+  const size_t px = (size_t)e->width * (size_t)e->height;
+  // whatever the engine's stream still does with the staging buffers (a previous upload) is over first
+  PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
+  int chunk = 0;
+  for (int done = 0; done < count; done += chunk_cap, chunk++) {
     const int c = count - done < chunk_cap ? count - done : chunk_cap;
-    st = stage_frames_h2d(e, e->d_gray, intensity + iframe_stride * (size_t)done, istride, iframe_stride, 1, c);
+    const int half = two_halves ? (chunk & 1) : 0;
+    const int off = half * chunk_cap;
+    if (chunk >= 2) PHOVO_HIP_CHECK(hipStreamWaitEvent(e->copy_stream, e->ev_built[half], 0));     // the half is free again
+    st = stage_frames_h2d(e, e->d_gray + px * (size_t)off, intensity + iframe_stride * (size_t)done, istride, iframe_stride, 1, c,
+                          e->copy_stream);
     if (st != PHOVO_OK) return st;
     if (kind == DEPTH_F64)
-      st = stage_frames_h2d(e, e->d_depth, static_cast<const char *>(depth) + dframe_stride * (size_t)done, dstride,
-                            dframe_stride, sizeof(double), c);
+      st = stage_frames_h2d(e, e->d_depth + px * (size_t)off, static_cast<const char *>(depth) + dframe_stride * (size_t)done,
+                            dstride, dframe_stride, sizeof(double), c, e->copy_stream);
     else if (kind == DEPTH_U16)
-      st = stage_frames_h2d(e, e->d_depth16, static_cast<const char *>(depth) + dframe_stride * (size_t)done, dstride,
-                            dframe_stride, sizeof(uint16_t), c);
+      st = stage_frames_h2d(e, e->d_depth16 + px * (size_t)off, static_cast<const char *>(depth) + dframe_stride * (size_t)done,
+                            dstride, dframe_stride, sizeof(uint16_t), c, e->copy_stream);
     if (st != PHOVO_OK) return st;
-    st = build_pyramids(e, first_frame + done, c, roles, kind, scale);
+    PHOVO_HIP_CHECK(hipEventRecord(e->ev_copied[half], e->copy_stream));
+    PHOVO_HIP_CHECK(hipStreamWaitEvent(e->stream, e->ev_copied[half], 0));
+    st = build_pyramids(e, first_frame + done, c, roles, kind, scale, off);
     if (st != PHOVO_OK) return st;
-    // the staging buffers are reused by the next chunk and the caller's buffers may be reused on return
-    PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
+    PHOVO_HIP_CHECK(hipEventRecord(e->ev_built[half], e->stream));
   }
+  // the caller's buffers may be reused on return, and the staging buffers by the next upload
+  PHOVO_HIP_CHECK(hipStreamSynchronize(e->copy_stream));
+  PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
   return PHOVO_OK;
 }
 

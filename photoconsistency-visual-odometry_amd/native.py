@@ -106,6 +106,8 @@ SYMBOLS = {
     "phovo_engine_set_iteration_cap": (C.c_int, [_vp, C.c_int]),
     "phovo_engine_set_slide_policy": (C.c_int, [_vp, C.c_int]),
     "phovo_engine_level_uses_wide": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "phovo_host_register": (C.c_int, [_vp, C.c_size_t]),
+    "phovo_host_unregister": (C.c_int, [_vp]),
     "phovo_engine_reserve_frames": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),
     "phovo_engine_level_size": (C.c_int, [_vp, C.c_int, _ip, _ip]),
     "phovo_engine_level_is_stored": (C.c_int, [_vp, C.c_int]),
