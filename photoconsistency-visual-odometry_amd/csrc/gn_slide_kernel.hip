@@ -166,8 +166,9 @@ __global__ __launch_bounds__(T, T / 256) void gn_level_kernel_slide(const GNLeve
     int inb_lo = 0, inb_hi = 0;
     // Software prefetch, B chunks (one whole phase) ahead in each pass: chunk b of a phase takes its operands from slot b
     // and refills the slot with chunk b of the NEXT phase.  Every wave then has 4 + 16 plane loads and 4 gathers in
-    // flight at all times (~12 KB; 8 waves per CU): the level is streamed from HBM, little of it stays in the Infinity
-    // Cache between iterations (2048 pairs x 3 MB), and one chunk ahead left the waves parked on s_waitcnt half the time.
+    // flight at all times (~12 KB; 8 waves per CU, ~96 KB per CU): the level is streamed from HBM -- little of it stays in
+    // the Infinity Cache between iterations (2048 pairs x 3 MB) -- and with 2 waves per SIMD there are few other waves to
+    // hide an HBM miss behind, so the distance is a whole phase rather than one chunk.
     double pzb[B], pz_s[B], gx_s[B], gy_s[B], i1_s[B];
 #pragma unroll
     for (int b = 0; b < B; b++) {
