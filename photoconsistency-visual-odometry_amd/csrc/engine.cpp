@@ -452,6 +452,7 @@ int phovo_engine_destroy(phovo_engine *e)
 {
   if (!e) return PHOVO_OK;
   (void)hipSetDevice(e->device);
+  if (e->copy_stream) (void)hipStreamSynchronize(e->copy_stream);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   free_pool(e);
   free_pairs(e);
@@ -741,28 +742,40 @@ static int upload_batch(phovo_engine *e, int first_frame, int count, int roles,
   const size_t px = (size_t)e->width * (size_t)e->height;
   // whatever the engine's stream still does with the staging buffers (a previous upload) is over first
   PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
+  // an error half way must not leave a copy from the caller's memory in flight when this function returns
+  auto drain = [&](int status) {
+    (void)hipStreamSynchronize(e->copy_stream);
+    (void)hipStreamSynchronize(e->stream);
+    return status;
+  };
+#define PHOVO_UPLOAD_CHECK(expr)                                                                              \
+  do {                                                                                                        \
+    hipError_t _e = (expr);                                                                                   \
+    if (_e != hipSuccess) return drain(fail(PHOVO_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e))); \
+  } while (0)
   int chunk = 0;
   for (int done = 0; done < count; done += chunk_cap, chunk++) {
     const int c = count - done < chunk_cap ? count - done : chunk_cap;
     const int half = two_halves ? (chunk & 1) : 0;
     const int off = half * chunk_cap;
-    if (chunk >= 2) PHOVO_HIP_CHECK(hipStreamWaitEvent(e->copy_stream, e->ev_built[half], 0));     // the half is free again
+    if (chunk >= 2) PHOVO_UPLOAD_CHECK(hipStreamWaitEvent(e->copy_stream, e->ev_built[half], 0));     // the half is free again
     st = stage_frames_h2d(e, e->d_gray + px * (size_t)off, intensity + iframe_stride * (size_t)done, istride, iframe_stride, 1, c,
                           e->copy_stream);
-    if (st != PHOVO_OK) return st;
+    if (st != PHOVO_OK) return drain(st);
     if (kind == DEPTH_F64)
       st = stage_frames_h2d(e, e->d_depth + px * (size_t)off, static_cast<const char *>(depth) + dframe_stride * (size_t)done,
                             dstride, dframe_stride, sizeof(double), c, e->copy_stream);
     else if (kind == DEPTH_U16)
       st = stage_frames_h2d(e, e->d_depth16 + px * (size_t)off, static_cast<const char *>(depth) + dframe_stride * (size_t)done,
                             dstride, dframe_stride, sizeof(uint16_t), c, e->copy_stream);
-    if (st != PHOVO_OK) return st;
-    PHOVO_HIP_CHECK(hipEventRecord(e->ev_copied[half], e->copy_stream));
-    PHOVO_HIP_CHECK(hipStreamWaitEvent(e->stream, e->ev_copied[half], 0));
+    if (st != PHOVO_OK) return drain(st);
+    PHOVO_UPLOAD_CHECK(hipEventRecord(e->ev_copied[half], e->copy_stream));
+    PHOVO_UPLOAD_CHECK(hipStreamWaitEvent(e->stream, e->ev_copied[half], 0));
     st = build_pyramids(e, first_frame + done, c, roles, kind, scale, off);
-    if (st != PHOVO_OK) return st;
-    PHOVO_HIP_CHECK(hipEventRecord(e->ev_built[half], e->stream));
+    if (st != PHOVO_OK) return drain(st);
+    PHOVO_UPLOAD_CHECK(hipEventRecord(e->ev_built[half], e->stream));
   }
+#undef PHOVO_UPLOAD_CHECK
   // the caller's buffers may be reused on return, and the staging buffers by the next upload
   PHOVO_HIP_CHECK(hipStreamSynchronize(e->copy_stream));
   PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
