@@ -592,6 +592,38 @@ def test_batched_upload_equals_per_frame_upload():
             eng.upload_frames(3 * F - 2, gray[:5], depth[:5])       # runs past the pool
 
 
+def test_upload_from_page_locked_caller_memory_and_many_chunks():
+    """phovo_host_register (hipHostRegister behind the C ABI) + a batched upload of 150 frames = five staging chunks through
+    the double-buffered path (copy stream beside the engine's stream): planes bit-identical to frame-by-frame uploads,
+    level-0 blur included; registering twice fails loudly, unregistering restores the buffer."""
+    F, w, h = 150, 160, 120
+    rs = np.random.RandomState(3)
+    gray = rs.randint(0, 256, size=(F, h, w)).astype(np.uint8)
+    d16 = rs.randint(0, 30000, size=(F, h, w)).astype(np.uint16)
+    ncfg, _ = _cfgs(3, [1, 1, 1], [0, 0, 0], blur=[3, 0, 5])
+    L = native.lib()
+    assert L.phovo_host_register(gray.ctypes.data, gray.nbytes) == 0
+    assert L.phovo_host_register(d16.ctypes.data, d16.nbytes) == 0
+    assert L.phovo_host_register(gray.ctypes.data, gray.nbytes) != 0          # already registered
+    assert L.phovo_host_register(None, 16) != 0
+    try:
+        with odometry.AlignmentEngine() as a, odometry.AlignmentEngine() as b:
+            for e in (a, b):
+                e.set_config(ncfg)
+                e.reserve_frames(F, w, h)
+            a.upload_frames(0, gray, d16, depth_scale=1.0 / 5000.0)
+            for f in range(F):
+                b.upload_frame_u16(f, gray[f], d16[f], 1.0 / 5000.0)
+            for f in (0, 31, 32, 63, 64, 95, 96, 128, 149):
+                for l in range(3):
+                    for x, y in zip(a.get_level_planes(f, l), b.get_level_planes(f, l)):
+                        np.testing.assert_array_equal(x, y)
+    finally:
+        assert L.phovo_host_unregister(gray.ctypes.data) == 0
+        assert L.phovo_host_unregister(d16.ctypes.data) == 0
+    assert L.phovo_host_unregister(gray.ctypes.data) != 0                       # no longer registered
+
+
 @pytest.mark.parametrize("size,expect", [
     ((40, 30), dict(threads=64, owner_in_lds=True, source_in_lds=False)),       # SOLO: one wave per pair, 16 per CU (TINY, 256
                                                                                 # threads with everything in LDS, for <= 8 pairs)
