@@ -595,7 +595,7 @@ def test_batched_upload_equals_per_frame_upload():
 def test_upload_from_page_locked_caller_memory_and_many_chunks():
     """phovo_host_register (hipHostRegister behind the C ABI) + a batched upload of 150 frames = five staging chunks through
     the double-buffered path (copy stream beside the engine's stream): planes bit-identical to frame-by-frame uploads,
-    level-0 blur included; registering twice fails loudly, unregistering restores the buffer."""
+    level-0 blur included; null arguments are refused."""
     F, w, h = 150, 160, 120
     rs = np.random.RandomState(3)
     gray = rs.randint(0, 256, size=(F, h, w)).astype(np.uint8)
@@ -604,7 +604,6 @@ def test_upload_from_page_locked_caller_memory_and_many_chunks():
     L = native.lib()
     assert L.phovo_host_register(gray.ctypes.data, gray.nbytes) == 0
     assert L.phovo_host_register(d16.ctypes.data, d16.nbytes) == 0
-    assert L.phovo_host_register(gray.ctypes.data, gray.nbytes) != 0          # already registered
     assert L.phovo_host_register(None, 16) != 0
     try:
         with odometry.AlignmentEngine() as a, odometry.AlignmentEngine() as b:
@@ -621,7 +620,6 @@ def test_upload_from_page_locked_caller_memory_and_many_chunks():
     finally:
         assert L.phovo_host_unregister(gray.ctypes.data) == 0
         assert L.phovo_host_unregister(d16.ctypes.data) == 0
-    assert L.phovo_host_unregister(gray.ctypes.data) != 0                       # no longer registered
 
 
 @pytest.mark.parametrize("size,expect", [
