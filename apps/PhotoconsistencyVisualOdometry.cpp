@@ -240,7 +240,7 @@ int main(int argc, char *argv[])
       // contiguous ranges (the first nPairs % nGpus ranges one pair longer), each range gets its own engine on its own
       // device and its own host thread, and needs the frames of its range plus one.  In ONE process the results meet
       // in host memory: no collective (the multi-process form, PhotoconsistencyVisualOdometrySharded.py, is where the
-      // RCCL all_gather is).  A pair's result does not depend on its batch, so the file is the same for every N.
+      // RCCL all_gather is).  With phovo_engine_set_batch_invariant a pair's result does not depend on its batch, so the file is the same for every N.
       const int nPairs = (int)nFrames - 1;
       std::vector<double> states((size_t)nPairs * 6);
       std::vector<std::string> shardError(nGpus);
@@ -254,6 +254,8 @@ int main(int argc, char *argv[])
         auto fail = [&](const char *what) { shardError[g] = std::string(what) + ": " + phovo_last_error(); if (engine) phovo_engine_destroy(engine); };
         if (phovo_engine_create(g % nDevices, &engine) != PHOVO_OK) return fail("phovo_engine_create");
         if (phovo_engine_set_config(engine, &cfg) != PHOVO_OK) return fail("phovo_engine_set_config");
+        // a pair's pose must not depend on the size of the shard it falls into (same trajectory file for every N)
+        if (phovo_engine_set_batch_invariant(engine, 1) != PHOVO_OK) return fail("phovo_engine_set_batch_invariant");
         if (phovo_engine_set_intrinsic_matrix(engine, intrinsicMatrix.data()) != PHOVO_OK) return fail("phovo_engine_set_intrinsic_matrix");
         if (phovo_engine_reserve_frames(engine, nf, W, H) != PHOVO_OK) return fail("phovo_engine_reserve_frames");
         if (phovo_engine_upload_frames_u16(engine, 0, nf, PHOVO_ROLE_BOTH, allGray.data() + (size_t)W * H * f0, (size_t)W,

@@ -72,6 +72,10 @@ typedef struct phovo_pair_report {
   double   gradient_norm;                /* ||J^T r|| of the last executed iteration (:380)      */
   uint32_t flags;                        /* PHOVO_PAIR_*                                         */
   uint32_t reserved;
+  int32_t  valid_pixels[PHOVO_MAX_LEVELS]; /* rows of J filled in the LAST executed iteration of each level: source
+                                            pixels that passed the depth gate (:280) and whose warp landed inside the
+                                            image (:302-303); 0 for a level with max_num_iterations == 0.  A handful of
+                                            them (a rank-deficient J^T J) is what precedes PHOVO_PAIR_NONFINITE.   */
 } phovo_pair_report;
 
 /* ---- extensions that are NOT in the reference (BASELINE.json configs[4]); all off by default -------------
@@ -209,17 +213,29 @@ int phovo_engine_set_wide_policy(phovo_engine *e, int policy);
  * by the exact kernel (owner map in HBM) for the pairs whose warp left the window.  policy: 0 = automatic (that), -1 =
  * exact kernel only.  Results are the same either way (tests/test_gpu_parity.py). */
 int phovo_engine_set_slide_policy(phovo_engine *e, int policy);
-/* With a gradient threshold (min_gradient_norm > 0) and more pairs than the GPU holds at once, a level runs as two
- * launches: every pair for at most `cap` iterations, then the pairs still running, all started together, to their end
- * (the few long pairs otherwise finish one per CU after the queue is empty).  Default 4; 0 = one launch.  Results are
- * bit-identical either way: the second launch continues from the stored state with the same kernel. */
+/* With a gradient threshold (min_gradient_norm > 0) and max_num_iterations above `cap`, a level that the persistent
+ * kernel takes in its throughput geometry (every batch of more than 8 pairs that does not go to the wide form; with
+ * phovo_engine_set_batch_invariant every batch) runs as two or three launches: every pair for at most `cap` iterations,
+ * then the pairs still running, all started together, to their end (the few long pairs otherwise finish one per CU
+ * after the queue is empty).  Default 4; 0 = one launch.  Iteration counts are identical either way and poses agree
+ * within the parity bar; the later launches use the geometry that runs ONE pair fastest, whose sums differ from the
+ * first launch's in their last bits (bit-identical only with PHOVO_GN_TAIL_SAME_PLAN=1, a test switch). */
 int phovo_engine_set_iteration_cap(phovo_engine *e, int cap);
+/* 1: a pair's result does not depend on how many other pairs are aligned with it -- every batch, whatever its size,
+ * takes the SAME kernels with the same geometries (no latency geometry for <= 8 pairs, no automatic wide form for
+ * <= 32 pairs, the capped launches of phovo_engine_set_iteration_cap for every batch), so a sequence cut into shards
+ * of any sizes gives bit-identical poses.  What the sequence drivers set (apps/PhotoconsistencyVisualOdometry --batch,
+ * sequence.py, bench.py).  0 (default): a handful of pairs takes the forms that finish soonest (same iteration counts,
+ * poses within the parity bar of the batch forms, last bits may differ). */
+int phovo_engine_set_batch_invariant(phovo_engine *e, int on);
 /* 1 if `level` would run in the wide form for a batch of n_pairs under the current settings. */
 int phovo_engine_level_uses_wide(const phovo_engine *e, int level, int n_pairs);
 
 /* Page-locks (and releases) a host buffer the caller will hand to the upload entry points repeatedly: uploads from
  * registered memory are direct DMA at the link rate instead of going through the runtime's bounce buffers.  Optional;
- * plain hipHostRegister / hipHostUnregister behind the C ABI for hosts that do not link the HIP runtime themselves. */
+ * hipHostRegister / hipHostUnregister behind the C ABI for hosts that do not link the HIP runtime themselves, with the
+ * library's own bookkeeping: registering a range that overlaps a registered one, and unregistering anything but the
+ * start of a registered range, return PHOVO_E_INVALID_ARGUMENT (thread-safe). */
 int phovo_host_register(void *ptr, size_t bytes);
 int phovo_host_unregister(void *ptr);
 

@@ -175,6 +175,49 @@ def normal_equations(planes, level, K, state, min_depth=0.3, max_depth=5.0):
     return g, Hm, r, J
 
 
+def scatter_statistics(planes, level, K, state, min_depth=0.3, max_depth=5.0):
+    """How hard one pass works the reference's scatter (`residuals(nCols*tr+tc) = ...`, ...Analytic.h:358, last raster
+    writer wins) on these planes: the number of source pixels that land in bounds, the target pixels hit, the fraction of
+    hit targets that more than one source lands on, the largest number of sources on one target, and the largest distance
+    (pixels) between two sources that collide: adjacent pixels of one surface collide at distance 1-2, pixels of
+    DIFFERENT depth layers (occlusion) from further apart -- `far_collisions` counts the targets whose sources are more
+    than 2 pixels apart.  Test coverage bookkeeping, not part of the algorithm."""
+    i0, d0 = planes[0], planes[1]
+    H_, W_ = i0.shape
+    sf = 1.0 / 2 ** level
+    fx, fy, ox, oy = K[0, 0] * sf, K[1, 1] * sf, K[0, 2] * sf, K[1, 2] * sf
+    x, y, z, yaw, pitch, roll = state
+    sy_, cy_, sp, cp, sr, cr = np.sin(yaw), np.cos(yaw), np.sin(pitch), np.cos(pitch), np.sin(roll), np.cos(roll)
+    R = np.array([[cy_ * cp, cy_ * sp * sr - sy_ * cr, cy_ * sp * cr + sy_ * sr],
+                  [sy_ * cp, sy_ * sp * sr + cy_ * cr, sy_ * sp * cr - cy_ * sr],
+                  [-sp, cp * sr, cp * cr]])
+    cc, rr = np.meshgrid(np.arange(W_, dtype=np.float64), np.arange(H_, dtype=np.float64))
+    pz = d0.reshape(-1)
+    valid = (min_depth < pz) & (pz < max_depth)
+    with np.errstate(all="ignore"):
+        px = (cc.reshape(-1) - ox) * pz / fx
+        py = (rr.reshape(-1) - oy) * pz / fy
+        P = np.stack([px, py, pz]) 
+        X, Y, Z = R @ P + np.array([[x], [y], [z]])
+        tci, tri = c_round(X * fx / Z + ox), c_round(Y * fy / Z + oy)
+        inb = valid & np.isfinite(tri) & np.isfinite(tci) & (tri >= 0) & (tri < H_) & (tci >= 0) & (tci < W_)
+    src = np.nonzero(inb)[0]
+    tgt = (tri[src] * W_ + tci[src]).astype(np.int64)
+    n = H_ * W_
+    count = np.bincount(tgt, minlength=n)
+    lo = np.full(n, n, dtype=np.int64)
+    hi = np.full(n, -1, dtype=np.int64)
+    np.minimum.at(lo, tgt, src)
+    np.maximum.at(hi, tgt, src)
+    hit = count > 0
+    multi = count > 1
+    # distance between the first and the last source of a target, in pixels (Chebyshev: rows or columns, whichever is larger)
+    span = np.where(multi, np.maximum(hi // W_ - lo // W_, np.abs(hi % W_ - lo % W_)), 0)
+    return dict(landed=int(inb.sum()), valid_fraction=float(valid.mean()), targets_hit=int(hit.sum()),
+                collision_fraction=float(multi.sum()) / max(1, int(hit.sum())), max_sources_per_target=int(count.max()),
+                max_collision_distance=int(span.max()), far_collisions=int((span > 2).sum()))
+
+
 def normal_equations_bilinear(planes, level, K, state, min_depth=0.3, max_depth=5.0, corrected=False):
     """EXTENSION (not in the reference's analytic path): forward-additive residuals / Jacobians with bilinear
     sampling at the real-valued warped position; rows belong to the source pixel.  Returns (r[N], J[N,6])."""

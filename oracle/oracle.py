@@ -41,6 +41,7 @@ class TraceEntry(C.Structure):
         ("level", C.c_int), ("iteration", C.c_int),
         ("gradient", C.c_double * 6), ("hessian", C.c_double * 36),
         ("state", C.c_double * 6),
+        ("valid_pixels", C.c_int), ("reserved", C.c_int),
     ]
 
 
@@ -261,8 +262,17 @@ def optimize(cfg, K, i0p, d0p, i1p, gxp, gyp, init_state=None, want_trace=False,
         trace.append(dict(level=e.level, iteration=e.iteration,
                           gradient=np.array(e.gradient[:]),
                           hessian=np.array(e.hessian[:]).reshape(6, 6),
-                          state=np.array(e.state[:])))
+                          state=np.array(e.state[:]), valid_pixels=int(e.valid_pixels)))
     return state, its, trace
+
+
+def valid_pixels_per_level(trace, num_levels):
+    """What the device path reports as phovo_pair_report.valid_pixels: the rows of J filled by the LAST executed
+    iteration of each level (0 for a level that executed none)."""
+    out = [0] * num_levels
+    for e in trace:
+        out[e["level"]] = e["valid_pixels"]
+    return out
 
 
 def align_frames(cfg, K, gray0, depth0, gray1, init_state=None, want_trace=False):

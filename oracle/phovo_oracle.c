@@ -226,6 +226,10 @@ void phovo_oracle_gaussian_blur_twice(double *img, int w, int h, int ksize)
   gaussian_blur_once(img, w, h, ksize);
 }
 
+/* Rows of J the last ComputeResidualsAndJacobians / compute_bilinear call on this thread filled (what the device
+ * path reports as phovo_pair_report.valid_pixels; the reference keeps no such count). */
+static _Thread_local int g_rows_filled;
+
 /* ------------------------------------------------------------------------- */
 /* ComputeResidualsAndJacobians: ...Analytic.h:191-367                        */
 /* ------------------------------------------------------------------------- */
@@ -291,6 +295,7 @@ void phovo_oracle_compute_residuals_and_jacobians(
   const double temp23 = cos(pitch) * sin(roll);
   const double temp24 = cos(pitch);
 
+  g_rows_filled = 0;
   for (int r = 0; r < nRows; r++) {                          /* raster order  :271-273 */
     for (int c = 0; c < nCols; c++) {
       const size_t i = (size_t)nCols * r + c;                /* :275 */
@@ -344,6 +349,7 @@ void phovo_oracle_compute_residuals_and_jacobians(
           const double gyi = lv->gy1[i];     /* :347 */
           for (int j = 0; j < 6; j++)        /* 1x2 * 2x6  :348 ; rows of J are column-major planes  :351-356 */
             jacobians[(size_t)j * n + i] = gxi * J[0][j] + gyi * J[1][j];
+          g_rows_filled++;
 
           residuals[(size_t)nCols * transformed_r_int + transformed_c_int] = pixel2 - pixel1;  /* scatter  :358 */
           if (warped) warped[(size_t)nCols * transformed_r_int + transformed_c_int] = pixel1;   /* :361 */
@@ -380,6 +386,7 @@ static void compute_bilinear(const phovo_oracle_level *lv, int level, const doub
   const double temp14 = cp * sy, temp15 = cp * cy, temp16 = sp * sr, temp17 = sp * cr;
   const double temp18 = cp * sr * sy, temp19 = cp * cr * sy, temp20 = sp * sy;
   const double temp21 = (cr * sy - sp * sr * cy), temp22 = cp * cr, temp23 = cp * sr, temp24 = cp;
+  g_rows_filled = 0;
   for (int r = 0; r < nRows; r++) {
     for (int c = 0; c < nCols; c++) {
       const size_t i = (size_t)nCols * r + c;
@@ -424,6 +431,7 @@ static void compute_bilinear(const phovo_oracle_level *lv, int level, const doub
       J[1][5] = fy * (pz * temp7 + py * temp9) * temp25 - fy * D * B * temp26;
       for (int j = 0; j < 6; j++) jacobians[(size_t)j * n + i] = smp[1] * J[0][j] + smp[2] * J[1][j];
       residuals[i] = smp[0] - lv->i0[i];
+      g_rows_filled++;
     }
   }
 }
@@ -582,6 +590,8 @@ static int optimize_impl(const phovo_oracle_config *cfg, const double k[9],
           memcpy(e->gradient, gradients, sizeof(gradients));
           memcpy(e->hessian, H, sizeof(H));
           memcpy(e->state, state, sizeof(double) * 6);
+          e->valid_pixels = g_rows_filled;
+          e->reserved = 0;
         }
         executed++;
       }

@@ -64,6 +64,8 @@ typedef struct phovo_oracle_trace_entry {
   double gradient[6];    /* J^T r (:538) */
   double hessian[36];    /* J^T J, row-major (:540) */
   double state[6];       /* state after the update (:539-540) */
+  int    valid_pixels;   /* rows of J this pass filled: depth gate (:280) and bounds (:302-303) passed */
+  int    reserved;
 } phovo_oracle_trace_entry;
 
 void phovo_oracle_default_config(phovo_oracle_config *cfg);

@@ -9,6 +9,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -103,6 +105,7 @@ struct phovo_engine {
   size_t wide_ws_capacity = 0;
   std::vector<int> h_wide_done;
   int wide_policy = 0;                         // 0 auto, 1 always (where possible), -1 never
+  bool batch_invariant = false;                // every batch takes the same kernels and geometries (phovo_engine_set_batch_invariant)
   int last_pairs = 0;
 };
 
@@ -169,6 +172,7 @@ bool use_wide_level(const phovo_engine *e, int n_pairs, int n_pixels)
   if (e->wide_policy < 0) return false;
   if (e->ext.plane_storage != PHOVO_STORAGE_F64 || e->ext.sampling != PHOVO_SAMPLING_NEAREST_SCATTER) return false;
   if (e->wide_policy > 0) return true;
+  if (e->batch_invariant) return false;        // the automatic choice looks at the batch size
   return n_pairs * 8 <= 256 && n_pixels >= 16384;
 }
 
@@ -231,7 +235,10 @@ int ensure_stage(phovo_engine *e, int frames, bool want_f64, bool want_u16)
     e->d_gray = nullptr; e->d_depth = nullptr; e->d_depth16 = nullptr; e->d_blur0 = nullptr;
     e->stage_frames = 0; e->stage_has_f64 = e->stage_has_u16 = false;
     PHOVO_HIP_CHECK(hipMalloc(&e->d_gray, px * (size_t)cap));
-    if (e->cfg.blur_filter_size[0] > 0) PHOVO_HIP_CHECK(hipMalloc(&e->d_blur0, px * (size_t)cap * sizeof(double)));
+    // (the blurred level-0 image of ONE chunk: build_pyramids uses it at offset 0 on the engine's stream, whichever
+    // staging half the chunk's raw frames sit in)
+    if (e->cfg.blur_filter_size[0] > 0)
+      PHOVO_HIP_CHECK(hipMalloc(&e->d_blur0, px * (size_t)(cap < STAGE_CHUNK ? cap : STAGE_CHUNK) * sizeof(double)));
     if (want_f64) PHOVO_HIP_CHECK(hipMalloc(&e->d_depth, px * (size_t)cap * sizeof(double)));
     if (want_u16) PHOVO_HIP_CHECK(hipMalloc(&e->d_depth16, px * (size_t)cap * sizeof(uint16_t)));
     e->stage_frames = cap; e->stage_has_f64 = want_f64; e->stage_has_u16 = want_u16;
@@ -577,6 +584,13 @@ int phovo_engine_set_iteration_cap(phovo_engine *e, int cap)
   return PHOVO_OK;
 }
 
+int phovo_engine_set_batch_invariant(phovo_engine *e, int on)
+{
+  if (!e) return fail(PHOVO_E_INVALID_ARGUMENT, "set_batch_invariant: null");
+  e->batch_invariant = on != 0;
+  return PHOVO_OK;
+}
+
 int phovo_engine_level_uses_wide(const phovo_engine *e, int level, int n_pairs)
 {
   if (!e || level < 0 || level >= e->cfg.num_levels || e->n_frames == 0) return 0;
@@ -595,17 +609,41 @@ int phovo_engine_set_build_all_levels(phovo_engine *e, int on)
   return PHOVO_OK;
 }
 
+// The ranges this library has page-locked, by start address.  The contract of the two entry points is the library's,
+// not the runtime's (which, depending on its version, accepts a second registration of a range or an unregister of a
+// pointer it never saw without saying so): a range that overlaps a registered one is refused, and so is an unregister
+// of anything but the start of a registered range.
+static std::mutex g_registry_mutex;
+static std::map<uintptr_t, size_t> g_registry;
+
 int phovo_host_register(void *ptr, size_t bytes)
 {
   if (!ptr || bytes == 0) return fail(PHOVO_E_INVALID_ARGUMENT, "host_register: null or empty");
+  const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
+  if (a + bytes < a) return fail(PHOVO_E_INVALID_ARGUMENT, "host_register: the range wraps around the address space");
+  std::lock_guard<std::mutex> lock(g_registry_mutex);
+  auto next = g_registry.lower_bound(a);                    // first registered range starting at or behind `a`
+  if (next != g_registry.end() && next->first < a + bytes)
+    return fail(PHOVO_E_INVALID_ARGUMENT, "host_register: the range overlaps one that is already registered");
+  if (next != g_registry.begin()) {
+    auto prev = std::prev(next);
+    if (prev->first + prev->second > a)
+      return fail(PHOVO_E_INVALID_ARGUMENT, "host_register: the range overlaps one that is already registered");
+  }
   PHOVO_HIP_CHECK(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+  g_registry[a] = bytes;
   return PHOVO_OK;
 }
 
 int phovo_host_unregister(void *ptr)
 {
   if (!ptr) return fail(PHOVO_E_INVALID_ARGUMENT, "host_unregister: null");
+  std::lock_guard<std::mutex> lock(g_registry_mutex);
+  auto it = g_registry.find(reinterpret_cast<uintptr_t>(ptr));
+  if (it == g_registry.end())
+    return fail(PHOVO_E_INVALID_ARGUMENT, "host_unregister: not the start of a range registered with phovo_host_register");
   PHOVO_HIP_CHECK(hipHostUnregister(ptr));
+  g_registry.erase(it);
   return PHOVO_OK;
 }
 
@@ -982,7 +1020,8 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
       PHOVO_HIP_CHECK(gn_run_level_wide(a, n_pairs, e->d_wide_ws, e->h_wide_done.data(), e->stream));
     } else {
       // a handful of pairs leaves most CUs empty: take the geometry with the shorter iteration (same owner-map placement)
-      const bool few = n_pairs <= LATENCY_PAIRS && lv.plan_few_ok && lv.plan_few.owner_in_lds == lv.plan.owner_in_lds;
+      const bool few = !e->batch_invariant && n_pairs <= LATENCY_PAIRS && lv.plan_few_ok &&
+                       lv.plan_few.owner_in_lds == lv.plan.owner_in_lds;
       const GNLaunchPlan &pl = few ? lv.plan_few : lv.plan;
       a.n_lds = pl.owner_in_lds ? 0 : pl.owner_lds_entries;
       const size_t hstride = pair_layout(n_pairs).handover_stride;
@@ -1005,8 +1044,9 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
         // state and iteration count, in the geometry that runs one pair fastest, and (where max_num_iterations allows)
         // caps them again at 3 x iter_cap for a third launch -- pairs of one launch then need about the same number
         // of iterations and finish together.  Every batch the persistent kernel takes in its throughput geometry goes
-        // this way, whatever its size, so that a pair's result does not depend on how many other pairs were aligned with
-        // it (a sequence gives the same trajectory file, byte for byte, on 1, 2 or 3 ranks: tests/test_sequence_sharded.py).
+        // this way; with batch_invariant that is EVERY batch, so that a pair's result does not depend on how many other
+        // pairs were aligned with it (a sequence gives the same trajectory file, byte for byte, however it is cut into
+        // shards: tests/test_sequence_sharded.py).
         a.handover_out = list0; a.iter_cap = e->iter_cap;
         PHOVO_HIP_CHECK(gn_launch_level(a, pl, e->ext.plane_storage, e->cu_count, e->stream));
         const GNLaunchPlan &tail = (!e->tail_same_plan && lv.plan_tail_ok && lv.plan_tail.owner_in_lds) ? lv.plan_tail : pl;

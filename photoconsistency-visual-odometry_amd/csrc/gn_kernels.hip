@@ -55,7 +55,8 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
   double *s_state = s_cst + 32;                                        // [8]
   double *s_red = s_state + 8;                                         // [NW][NRED]
   int *s_ctl = reinterpret_cast<int *>(s_red + NW * NRED);             // [CTL_COUNT]
-  unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(s_ctl + CTL_COUNT);  // [n_chunks] (!MASK_REG)
+  int *s_next = s_ctl + CTL_COUNT;                                     // [NX_COUNT] look-ahead block (gn_device.hpp)
+  unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(s_next + NX_COUNT);  // [n_chunks] (!MASK_REG)
   unsigned char *p = reinterpret_cast<unsigned char *>(s_mask + (MASK_REG ? 0 : A.n_chunks));
   int *s_owner = reinterpret_cast<int *>(p);                           // [n] (OWNER_LDS) or [n_lds] (owner map in HBM)
   if (OWNER_LDS) p += sizeof(int) * ((A.n + 1) & ~1);
@@ -67,28 +68,40 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
   // wave-uniform by construction; saying so lets the chunk loops run on the scalar unit (s_cmp / s_cbranch)
   // instead of exec-masked vector compares
   const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
+  constexpr int PFW = NW - 1;       // the wave that looks ahead (not wave 0: that one has the serial section of every iteration)
+  constexpr bool GLOBAL_SYNC = !OWNER_LDS;    // waves exchange owner entries through HBM: barriers keep their fence
   const int n = A.n, W = A.w, H = A.h;
   // Work queue: the grid has as many workgroups as fit the chip; each draws pair after pair from an atomic counter.
   // Pairs stop after data-dependent iteration counts and the hardware deals blocks to the 8 XCDs round-robin, so a
   // one-block-per-pair grid leaves whole XCDs idle while another one still works through its long pairs.
-  // Thread 0 draws the next index in the same block that writes the finished pair back, so that the only thing between
-  // the iteration loop and the barrier at the head of the work loop is one if-block (two adjacent `if (tid == 0)`
-  // blocks, one either side of the back edge, were threaded together by the compiler into a loop that reached that
-  // barrier with thread 0 parked: a hang).
-  // (draw_pair_any: with handover_in the pairs come from the list an earlier launch of this level left behind)
-  if (tid == 0) s_ctl[CTL_PAIR] = draw_pair_any(A);
+  // The descriptor of a pair (index, frames, state, starting iteration) reaches the workgroup through the look-ahead
+  // block in LDS, ONE PAIR AHEAD (gn_device.hpp): wave PFW draws the ticket and requests the descriptor during the
+  // first iteration of the pair before; for the very first pair it does so here.  (With handover_in the pairs come from
+  // the list an earlier launch of this level left behind.)
+  // The owner map in LDS is wiped ONCE per workgroup: pass 2 resets every slot it reads, and it reads all of them.
+  for (int k = tid; k < (OWNER_LDS ? n : n_lds); k += T) s_owner[k] = -1;
+  if (wave == PFW) {
+    int first_pair = 0;
+    if (lane == 0) first_pair = draw_end(A, draw_begin(A));
+    first_pair = __builtin_amdgcn_readfirstlane(first_pair);
+    lookahead_store(A, first_pair, lookahead_load(A, first_pair, lane), lane, s_next);
+  }
   for (;;) {
-  // The ticket thread 0 has just stored must have LEFT its LDS queue before any wave is released: the compiler omits
+  // What the look-ahead wave has stored must have LEFT its LDS queue before any wave is released: the compiler omits
   // the wait in front of this one barrier (it relies on LDS operations being ordered across waves), and on the GPU
   // about one wave in 10^5 then read the previous ticket and aligned the wrong pair's pixels into this pair's sums --
   // or, on the last round, would never have left the loop.  Found by test_work_queue_results_do_not_depend_on_...
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __syncthreads();
-  const int pair = __builtin_amdgcn_readfirstlane(s_ctl[CTL_PAIR]);
+  // (wg_barrier says the wait explicitly.)
+  wg_barrier<NW, GLOBAL_SYNC>();
+  const int pair = __builtin_amdgcn_readfirstlane(s_next[NX_PAIR]);
   if (pair >= A.n_pairs) break;           // uniform: every wave of the workgroup leaves together
+  const int pair_src = __builtin_amdgcn_readfirstlane(s_next[NX_SRC]);
+  const int pair_tgt = __builtin_amdgcn_readfirstlane(s_next[NX_TGT]);
+  // continuing a pair an earlier launch handed over: its completed iterations count
+  const int it0 = A.handover_in ? __builtin_amdgcn_readfirstlane(s_next[NX_IT]) : 0;
 
-  const unsigned char *src_frame = A.planes + (size_t)A.src[pair] * A.frame_bytes;
-  const unsigned char *tgt_frame = A.planes + (size_t)A.tgt[pair] * A.frame_bytes;
+  const unsigned char *src_frame = A.planes + (size_t)pair_src * A.frame_bytes;
+  const unsigned char *tgt_frame = A.planes + (size_t)pair_tgt * A.frame_bytes;
   int *g_owner = OWNER_LDS ? nullptr : A.g_owner + (size_t)pair * (size_t)n;
   const __amdgpu_buffer_rsrc_t rI0 = plane_rsrc<TI>(src_frame + A.plane_off[PLANE_I], n);
   const __amdgpu_buffer_rsrc_t rD0 = plane_rsrc<TD>(src_frame + A.plane_off[PLANE_D], n);
@@ -96,14 +109,27 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
   const __amdgpu_buffer_rsrc_t rGX = plane_rsrc<TI>(tgt_frame + A.plane_off[PLANE_GX], n);
   const __amdgpu_buffer_rsrc_t rGY = plane_rsrc<TI>(tgt_frame + A.plane_off[PLANE_GY], n);
 
+  // Pass 1 keeps PD depth chunks per wave in flight (a ring of PD registers).  One chunk ahead -- 1 KB per wave -- was
+  // enough while the planes come from the Infinity Cache, but the FIRST iteration of a pair reads them from HBM, where 16
+  // waves per CU with 1 KB each in flight are good for ~2 TB/s chip-wide (Little's law at ~2 us): with the shipped
+  // thresholds (3 iterations per pair on average) that first pass was a sixth of a pair's time.  The ring of the first
+  // iteration is requested HERE, in front of the prologue (pose constants, a barrier), and the ring of every later
+  // iteration right behind pass 2 of the one before, in front of the reduction and wave 0's solve: no pass starts on an
+  // empty pipeline.
+  constexpr int PD = 4;
+  double pzr[PD];
+#ifdef PHOVO_AB_PREISSUE
+  if constexpr (OWNER_LDS) {
+#pragma unroll
+    for (int i = 0; i < PD; i++) pzr[i] = plane_load<TD>(rD0, wave * WAVE + lane + i * NW * WAVE);   // past the plane: 0
+  }
+#endif
+
   // ---- level prologue -------------------------------------------------------------------
-  if (OWNER_LDS) {
-    for (int k = tid; k < n; k += T) s_owner[k] = -1;
-  } else {
+  if (!OWNER_LDS) {
     // Owner map in HBM: entries carry the iteration they were written in (OWNER_TAG_SHIFT), so nothing has to be
     // reset between iterations; it is wiped once per pair here (the barrier below waits for the stores, and the
     // map is touched by this workgroup only).
-    for (int k = tid; k < n_lds; k += T) s_owner[k] = -1;
     for (int k = n_lds + tid; k < n; k += T) g_owner[k] = -1;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   }
@@ -113,7 +139,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
   if (wave == 0) {
     double st[6];
 #pragma unroll
-    for (int j = 0; j < 6; j++) st[j] = A.states[(size_t)pair * 6 + j];
+    for (int j = 0; j < 6; j++) st[j] = reinterpret_cast<const double *>(s_next + NX_STATE)[j];
     write_pose_constants(st[0], st[1], st[2], st[3], st[4], st[5], s_cst, lane);
     if (lane == 0) {
 #pragma unroll
@@ -122,7 +148,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
       s_ctl[CTL_FLAGS] = 0;
     }
   }
-  __syncthreads();
+  wg_barrier<NW, GLOBAL_SYNC>();
 
   const double fx = A.fx, fy = A.fy, ox = A.ox, oy = A.oy, ifx = A.ifx, ify = A.ify;
   const double min_d = A.min_depth, max_d = A.max_depth;
@@ -137,15 +163,26 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
   // A wave walks the image in chunks of 64 consecutive pixels, NW chunks apart; (row, column) of a
   // lane's pixel is carried along instead of divided out per pixel.
   const int k0 = wave * WAVE + lane;
-  const int r0 = k0 / W, c0 = k0 - r0 * W;
   const int step_r = (NW * WAVE) / W, step_c = (NW * WAVE) - step_r * W;
   const RowColStep rc_step = make_rowcol_step(step_r, step_c, W);
-  const double cd0 = (double)c0, rd0 = (double)r0;
+  // (row, column) of the lane's first pixel, worked out at the head of EACH pass (five fp64 instructions) instead of
+  // once per pair: kept in registers across pass 2 -- which sits at the 128-register cap -- they were spilled, and their
+  // reloads in front of pass 1's loop made every wait inside that loop a wait for everything in flight.
+  // row = trunc((k + 0.5) / W): (k + 0.5) / W is at least 0.5 / W away from an integer, far more than the rounding of the
+  // product; column = k - row * W is exact.
+  const double inv_w = uniform_f64(1.0 / dW);
+  auto first_rowcol = [&](double &cd, double &rd) {
+    int kk = k0;
+    asm volatile("" : "+v"(kk));                  // (opaque: the compiler would hoist the result out of the iteration loop and spill it)
+    const double kd = (double)kk;
+    rd = trunc((kd + 0.5) * inv_w);
+    cd = fma(-rd, dW, kd);
+  };
 
-  int iteration = 0;                // continuing a pair an earlier launch handed over: its completed iterations count
-  if (A.handover_in) iteration = __builtin_amdgcn_readfirstlane(A.reports[pair].iterations[A.level]);
+  int iteration = it0;
   bool handed_over = false;
   double last_gnorm = 0.0;
+  int last_valid = 0;
 #ifdef PHOVO_STAMPS
   unsigned long long st_sum[5] = {0, 0, 0, 0, 0};
   unsigned long long st_prev = clock64();
@@ -185,12 +222,22 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
     // MASK_REG: chunk j's "landed in bounds" ballot lives in lane j of two registers (v_writelane here, v_readlane
     // + exec mask in pass 2): no per-lane shifting and masking in either pass
     int inb_lo = 0, inb_hi = 0;
+    int n_rows = 0;                 // Jacobian rows this wave fills in this iteration (scalar unit: popcount of the ballots)
     {
       int k = k0, j = 0;
-      double cd = cd0, rd = rd0;
+      asm volatile("" : "+v"(k));                   // (opaque, like first_rowcol's: nothing derived from it leaves the iteration loop)
+      double cd, rd;
+      first_rowcol(cd, rd);
       // software prefetch: the depth of the NEXT chunk is requested before this chunk is processed, so
       // every wave keeps a load in flight while it computes (the passes are bound by bytes in flight per CU)
-      double pz_next = plane_load<TD>(rD0, k);
+      double pz_next = 0.0;
+      if constexpr (!OWNER_LDS) pz_next = plane_load<TD>(rD0, k);
+#ifndef PHOVO_AB_PREISSUE       // A/B diagnostic build only: the ring is filled here, at the head of the pass
+      if constexpr (OWNER_LDS) {
+#pragma unroll
+        for (int i = 0; i < PD; i++) pzr[i] = plane_load<TD>(rD0, k + i * NW * WAVE);
+      }
+#endif
       // the translation sits in vector registers during this pass (pass 1 has registers to spare): an fma takes one
       // scalar operand, and the rotation entry already is one
       double cxv = cx, cyv = cyy, czv = cz;
@@ -223,6 +270,9 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
         t_out = (int)fma(rr, dW, rc);                                     // exact in fp64: one fma + one conversion
       };
       auto keep_mask = [&](const unsigned long long m, const int chunk) {
+#ifndef PHOVO_AB_NO_ROWS
+        n_rows += __builtin_popcountll(m);
+#endif
         if (MASK_REG) {
           inb_lo = writelane_b32(inb_lo, (int)(unsigned)m, j);
           inb_hi = writelane_b32(inb_hi, (int)(unsigned)(m >> 32), j);
@@ -231,26 +281,63 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
         }
       };
       if constexpr (OWNER_LDS) {
-        auto chunk_body = [&](const int chunk) {
-          const double pz = pz_next;                                      // :279
-          pz_next = plane_load<TD>(rD0, k + NW * WAVE);                   // past the plane: 0
+        auto chunk_body = [&](const int chunk, double &slot) {
           unsigned long long m;
           int t;
-          warp_chunk(pz, m, t);
+          warp_chunk(slot, m, t);                                         // :279
+          // The slot is refilled BEHIND the last use of its value, into the same register: requested in front of it the
+          // new value needs a second register and a copy at the loop's back edge -- which waits for every load in
+          // flight (the ring would run empty once per trip).
+          __builtin_amdgcn_sched_barrier(0);
+          slot = plane_load<TD>(rD0, k + PD * NW * WAVE);                 // this slot's next chunk (past the plane: 0)
           if (__builtin_amdgcn_inverse_ballot_w64(m)) atomicMax(&s_owner[t], k);     // last raster writer wins  :358
           keep_mask(m, chunk);
           k += NW * WAVE;
           j++;
           rowcol_advance(cd, rd, rc_step);
+          __builtin_amdgcn_sched_barrier(0);    // (and the next chunk's first instructions -- they wait for ITS slot -- stay behind)
         };
-        // two chunks per trip, written out by hand: the ballot / lane accesses are convergent operations, which the
-        // compiler will not duplicate for a run-time trip count (#pragma unroll is refused); the bounds are wave-uniform
+        // PD chunks per trip (one per ring slot), written out by hand: the ballot / lane accesses are convergent
+        // operations, which the compiler will not duplicate for a run-time trip count (#pragma unroll is refused); the
+        // bounds are wave-uniform
+        static_assert(PD == 4, "the trips below are written out for four slots");
         int chunk = wave;
-        for (; chunk + NW < A.n_chunks; chunk += 2 * NW) {
-          chunk_body(chunk);
-          chunk_body(chunk + NW);
+#ifdef PHOVO_AB_CLASSIC_PASS1       // A/B diagnostic build only: one chunk ahead, two chunks per trip, free scheduling (round 2)
+        {
+          double pz_n1 = pzr[0];
+          auto classic_body = [&](const int ch) {
+            const double pz = pz_n1;
+            pz_n1 = plane_load<TD>(rD0, k + NW * WAVE);
+            unsigned long long m;
+            int t;
+            warp_chunk(pz, m, t);
+            if (__builtin_amdgcn_inverse_ballot_w64(m)) atomicMax(&s_owner[t], k);
+            keep_mask(m, ch);
+            k += NW * WAVE;
+            j++;
+            rowcol_advance(cd, rd, rc_step);
+          };
+          for (; chunk + NW < A.n_chunks; chunk += 2 * NW) {
+            classic_body(chunk);
+            classic_body(chunk + NW);
+          }
+          if (chunk < A.n_chunks) classic_body(chunk);
+          chunk = A.n_chunks;
         }
-        if (chunk < A.n_chunks) chunk_body(chunk);
+#endif
+        for (; chunk + 3 * NW < A.n_chunks; chunk += 4 * NW) {
+          chunk_body(chunk, pzr[0]);
+          chunk_body(chunk + NW, pzr[1]);
+          chunk_body(chunk + 2 * NW, pzr[2]);
+          chunk_body(chunk + 3 * NW, pzr[3]);
+        }
+        if (chunk < A.n_chunks) {
+          chunk_body(chunk, pzr[0]);
+          if (chunk + NW < A.n_chunks) {
+            chunk_body(chunk + NW, pzr[1]);
+            if (chunk + 2 * NW < A.n_chunks) chunk_body(chunk + 2 * NW, pzr[2]);
+          }
+        }
       } else {
         // Owner map in HBM.  The memory counter of a wave retires in order, so a load issued behind a global atomic
         // waits for that atomic (about 2800 cycles with every CU issuing them): a loop of load - compute - atomic per
@@ -296,8 +383,21 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
         }
       }
     }
+    // The four planes of pass 2's first chunk do not depend on the owner map: they are requested in FRONT of the barrier
+    // (the owner and the gather it leads to follow behind it).
+    int o_n = -1;
+    double pz_n = 0.0, gx_n = 0.0, gy_n = 0.0, i1_n = 0.0, i0_n = 0.0;
+    auto fetch_planes = [&](int kk) {
+      pz_n = plane_load<TD>(rD0, kk);
+      gx_n = plane_load<TI>(rGX, kk);             // gradient at the SOURCE index  :346-347
+      gy_n = plane_load<TI>(rGY, kk);
+      i1_n = plane_load<TI>(rI1, kk);             // :309
+    };
+#ifdef PHOVO_AB_PREISSUE
+    if constexpr (OWNER_LDS) fetch_planes(k0);
+#endif
     PHOVO_STAMP(0)
-    __syncthreads();
+    wg_barrier<NW, GLOBAL_SYNC>();
     PHOVO_STAMP(1)
 
     // ---- pass 2: residual, Jacobian row, normal-equation accumulation ---------------------
@@ -316,11 +416,11 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
     auto pass2 = [&](auto huber_tag) {
       constexpr bool HUBER = decltype(huber_tag)::value;
       int k = k0, j = 0;
-      double cd = cd0, rd = rd0;
+      asm volatile("" : "+v"(k));
+      double cd, rd;
+      first_rowcol(cd, rd);
       // software prefetch, as in pass 1: owner + four planes of the NEXT chunk are requested (and the
       // gathered source intensity right behind them) before this chunk's arithmetic starts.
-      int o_n = -1;
-      double pz_n = 0.0, gx_n = 0.0, gy_n = 0.0, i1_n = 0.0, i0_n = 0.0;
       // Owner map in HBM: the entry is requested TWO chunks ahead (o_raw), so that the gather of the source
       // intensity one chunk ahead starts from an index that has already arrived instead of stalling on it; entries
       // of earlier iterations fail the tag comparison, so nothing is written back (a store per chunk would hold up
@@ -330,7 +430,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
         o_raw = (kk >= n_lds && kk < n) ? __hip_atomic_load(&g_owner[kk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
       };
       if (!OWNER_LDS) owner_request(k);
-      auto fetch = [&](int kk) {
+      auto fetch_owner = [&](int kk) {
         o_n = -1;
         if (OWNER_LDS) {
           if (kk < n) {
@@ -346,14 +446,27 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
           }
           owner_request(kk + NW * WAVE);
         }
-        pz_n = plane_load<TD>(rD0, kk);
-        gx_n = plane_load<TI>(rGX, kk);             // gradient at the SOURCE index  :346-347
-        gy_n = plane_load<TI>(rGY, kk);
-        i1_n = plane_load<TI>(rI1, kk);             // :309
+      };
+      auto gather_source = [&]() {
         if (SRC_LDS) { if (o_n >= 0) i0_n = s_i0[o_n]; }
         else i0_n = plane_load<TI>(rI0, o_n);       // :308 of the owning source pixel (o = -1: offset past the plane -> 0)
       };
+      auto fetch = [&](int kk) {
+        fetch_owner(kk);
+        fetch_planes(kk);
+        gather_source();
+      };
+#ifdef PHOVO_AB_PREISSUE
+      if constexpr (OWNER_LDS) {                    // the planes of the first chunk are on their way since before the barrier
+        fetch_owner(k);
+        gather_source();
+      } else {
+        fetch(k);
+      }
+#else
       fetch(k);
+#endif
+
       auto chunk_body = [&](const int chunk) {
         const int o = o_n;
         const double pz = pz_n, gxi = gx_n, gyi = gy_n, pixel2 = i1_n, pixel1 = i0_n;
@@ -426,6 +539,16 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
       }
     };
     if (huber_on) pass2(std::true_type{}); else pass2(std::false_type{});
+#ifndef PHOVO_AB_NO_VALID
+    acc[RED_VALID] = lane == 0 ? (double)n_rows : 0.0;
+#endif
+    // the depth ring of the NEXT iteration's pass 1 (the same chunks again; wasted if this was the pair's last iteration)
+#ifdef PHOVO_AB_PREISSUE
+    if constexpr (OWNER_LDS) {
+#pragma unroll
+      for (int i = 0; i < PD; i++) pzr[i] = plane_load<TD>(rD0, k0 + i * NW * WAVE);
+    }
+#endif
 
     PHOVO_STAMP(2)
     // ---- wave-level transposed butterfly: 32 shuffles, lane l ends with value index idx(l) ----
@@ -440,7 +563,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
                       ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
       if ((lane & 1) == 0) s_red[wave * NRED + idx] = total;
     }
-    __syncthreads();
+    wg_barrier<NW, false>();
     PHOVO_STAMP(3)
 
     // ---- wave 0: cross-wave sum (fixed order), solve, update, terminate ------------------------
@@ -463,6 +586,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
 #pragma unroll
       for (int i = 0; i < 6; i++) g[i] = __shfl(v, 21 + i, WAVE);
 
+      last_valid = (int)__shfl(v, RED_VALID, WAVE);
       PHOVO_SUBSTAMP(0)
       double step[6];
       solve6_ldlt(h, g, step);
@@ -496,7 +620,17 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
       }
       last_gnorm = gnorm;
     }
-    __syncthreads();
+    // Look-ahead, first iteration of a pair only: while wave 0 solves, the last wave -- idle at the barrier below
+    // otherwise -- draws the NEXT pair's ticket and fetches its descriptor (state, frame indices, starting iteration: one
+    // dword per lane) into the look-ahead block.  Two dependent trips to memory, in the shadow of the serial section; what
+    // the next pair's prologue finds is all in LDS.
+    if (wave == PFW && iteration == it0) {                                  // wave-uniform
+      int next_pair = 0;
+      if (lane == 0) next_pair = draw_end(A, draw_begin(A));
+      next_pair = __builtin_amdgcn_readfirstlane(next_pair);
+      lookahead_store(A, next_pair, lookahead_load(A, next_pair, lane), lane, s_next);
+    }
+    wg_barrier<NW, false>();
     PHOVO_STAMP(4)
     iteration++;
     const int done_word = s_ctl[CTL_DONE];
@@ -510,8 +644,10 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
     if (A.reports) {
       A.reports[pair].iterations[A.level] = iteration;
       A.reports[pair].gradient_norm = last_gnorm;
-      A.reports[pair].flags |= (uint32_t)s_ctl[CTL_FLAGS];
-      if (A.handover_in) A.reports[pair].flags |= A.takeover_flag;
+      A.reports[pair].valid_pixels[A.level] = last_valid;
+      // (a flag is rare: an atomic without return instead of a read-modify-write that thread 0 would wait for)
+      const uint32_t new_flags = (uint32_t)s_ctl[CTL_FLAGS] | (A.handover_in ? A.takeover_flag : 0u);
+      if (new_flags) atomicOr(&A.reports[pair].flags, new_flags);
 #ifdef PHOVO_STAMPS
       // diagnostic build only: phase cycle sums of wave 0 go to the otherwise unused report slots 8..12
       for (int j = 0; j < 5; j++) A.reports[pair].iterations[8 + j] = (int)(st_sum[j] / (unsigned long long)iteration);
@@ -523,7 +659,6 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
 #endif
     }
     if (handed_over) handover_append(A, pair);
-    s_ctl[CTL_PAIR] = draw_pair_any(A);
   }
   }   // next pair
 }
@@ -592,6 +727,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel_bilinear(const GNLevel
 
   int iteration = 0;
   double last_gnorm = 0.0;
+  int last_valid = 0;
   while (true) {
     const double cx = uniform_f64(s_cst[C_X]), cyy = uniform_f64(s_cst[C_Y]), cz = uniform_f64(s_cst[C_Z]);
     const double r01 = uniform_f64(s_cst[C_R01]), r02 = uniform_f64(s_cst[C_R02]);
@@ -662,7 +798,9 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel_bilinear(const GNLevel
       k += NW * WAVE;
       rowcol_advance(cd, rd, rc_step);
     };
+    int n_rows = 0;
     auto consume = [&](const Warped &w) {
+      n_rows += __builtin_popcountll(w.m);
       if (__builtin_amdgcn_inverse_ballot_w64(w.m)) {
         const double px = w.px, py = w.py, pz = w.pz, Zr = w.Zr, t25 = w.t25, ax = w.ax, ay = w.ay;
         auto sample = [&](int b) {
@@ -721,8 +859,9 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel_bilinear(const GNLevel
         }
       }
     }
+    acc[RED_VALID] = lane == 0 ? (double)n_rows : 0.0;
     reduce_solve_update<NW>(acc, lane, wave, s_red, s_state, s_cst, s_ctl, A.lambda, A.max_iter, A.min_grad_norm,
-                            iteration, last_gnorm);
+                            iteration, last_gnorm, last_valid);
     iteration++;
     if (s_ctl[CTL_DONE]) break;
   }
@@ -732,6 +871,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel_bilinear(const GNLevel
     if (A.reports) {
       A.reports[pair].iterations[A.level] = iteration;
       A.reports[pair].gradient_norm = last_gnorm;
+      A.reports[pair].valid_pixels[A.level] = last_valid;
       A.reports[pair].flags |= (uint32_t)s_ctl[CTL_FLAGS];
     }
     s_ctl[CTL_PAIR] = draw_pair(A.work_counter, A.n_queues, A.n_pairs);
@@ -745,7 +885,7 @@ constexpr size_t LDS_HALF = LDS_LIMIT / 2; // two workgroups per CU
 size_t lds_fixed_bytes(int threads)
 {
   const int nw = threads / WAVE;
-  return sizeof(double) * (32 + 8 + (size_t)nw * NRED) + sizeof(int) * CTL_COUNT;
+  return sizeof(double) * (32 + 8 + (size_t)nw * NRED) + sizeof(int) * (CTL_COUNT + NX_COUNT);   // (+ the look-ahead block)
 }
 
 static_assert((1 << OWNER_TAG_SHIFT) - 1 == OWNER_INDEX_MASK, "index mask and tag shift belong together");

@@ -124,6 +124,7 @@ __global__ __launch_bounds__(T, T / 256) void gn_level_kernel_slide(const GNLeve
 
   int iteration = 0;
   double last_gnorm = 0.0;
+  int last_valid = 0;
   bool handed_over = false;
   while (true) {
     // ---- constants of this iteration ----------------------------------------------------------------------
@@ -164,6 +165,7 @@ __global__ __launch_bounds__(T, T / 256) void gn_level_kernel_slide(const GNLeve
     double cd2 = cd2_0, rd2 = rd2_0;
     // chunk j's "valid and landed in bounds" ballot lives in lane (j & 63) of two registers from pass 1 to pass 2
     int inb_lo = 0, inb_hi = 0;
+    int n_rows = 0;                 // Jacobian rows this wave fills in this iteration (popcount of the ballots, scalar unit)
     // Software prefetch, B chunks (one whole phase) ahead in each pass: chunk b of a phase takes its operands from slot b
     // and refills the slot with chunk b of the NEXT phase.  Every wave then has 4 + 16 plane loads and 4 gathers in
     // flight at all times (~12 KB; 8 waves per CU, ~96 KB per CU): the level is streamed from HBM -- little of it stays in
@@ -202,6 +204,7 @@ __global__ __launch_bounds__(T, T / 256) void gn_level_kernel_slide(const GNLeve
         if (lane == 0) s_ctl[CTL_OOW] = 1;
         m &= inside;
       }
+      n_rows += __builtin_popcountll(m);
       if (__builtin_amdgcn_inverse_ballot_w64(m)) atomicMax(&s_owner[t & (SLIDE_RING_PX - 1)], k1);   // :358
       inb_lo = writelane_b32(inb_lo, (int)(unsigned)m, j1 & 63);
       inb_hi = writelane_b32(inb_hi, (int)(unsigned)(m >> 32), j1 & 63);
@@ -309,6 +312,7 @@ __global__ __launch_bounds__(T, T / 256) void gn_level_kernel_slide(const GNLeve
     }
     };
     if (huber_on) run_phases(std::true_type{}); else run_phases(std::false_type{});
+    acc[RED_VALID] = lane == 0 ? (double)n_rows : 0.0;
 
     // ---- wave-level transposed butterfly, cross-wave sum, solve, update, terminate (as gn_level_kernel) ---
     reduce_stage_swap<32, false>(acc);
@@ -337,6 +341,7 @@ __global__ __launch_bounds__(T, T / 256) void gn_level_kernel_slide(const GNLeve
       for (int q = 0; q < 21; q++) h[q] = __shfl(v, q, WAVE);
 #pragma unroll
       for (int i = 0; i < 6; i++) g[i] = __shfl(v, 21 + i, WAVE);
+      const int n_valid = (int)__shfl(v, RED_VALID, WAVE);
       const bool void_iteration = s_ctl[CTL_OOW] != 0;                  // wave-uniform
       double step[6];
       solve6_ldlt(h, g, step);
@@ -368,6 +373,7 @@ __global__ __launch_bounds__(T, T / 256) void gn_level_kernel_slide(const GNLeve
           if (!finite) s_ctl[CTL_FLAGS] |= (int)PHOVO_PAIR_NONFINITE;
         }
         last_gnorm = gnorm;
+        last_valid = n_valid;
       }
     }
     __syncthreads();
@@ -384,6 +390,7 @@ __global__ __launch_bounds__(T, T / 256) void gn_level_kernel_slide(const GNLeve
     if (A.reports) {
       A.reports[pair].iterations[A.level] = iteration;                  // completed iterations (the exact kernel resumes here)
       A.reports[pair].gradient_norm = last_gnorm;
+      A.reports[pair].valid_pixels[A.level] = last_valid;
       A.reports[pair].flags |= (uint32_t)s_ctl[CTL_FLAGS];
     }
     if (handed_over) handover_append(A, pair);

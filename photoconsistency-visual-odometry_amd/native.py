@@ -16,6 +16,8 @@ MAX_LEVELS = 16
 ROLE_SOURCE, ROLE_TARGET, ROLE_BOTH = 1, 2, 3
 PAIR_NONFINITE = 1
 PAIR_WINDOW_FALLBACK = 2
+# phovo_status
+OK, E_INVALID_ARGUMENT, E_CONFIG, E_SHAPE, E_HIP, E_NOT_READY, E_IO, E_UNSUPPORTED = range(8)
 
 
 class PhovoError(RuntimeError):
@@ -56,6 +58,7 @@ class PairReport(C.Structure):
         ("gradient_norm", C.c_double),
         ("flags", C.c_uint32),
         ("reserved", C.c_uint32),
+        ("valid_pixels", C.c_int32 * MAX_LEVELS),
     ]
 
 
@@ -104,6 +107,7 @@ SYMBOLS = {
     "phovo_engine_set_build_all_levels": (C.c_int, [_vp, C.c_int]),
     "phovo_engine_set_wide_policy": (C.c_int, [_vp, C.c_int]),
     "phovo_engine_set_iteration_cap": (C.c_int, [_vp, C.c_int]),
+    "phovo_engine_set_batch_invariant": (C.c_int, [_vp, C.c_int]),
     "phovo_engine_set_slide_policy": (C.c_int, [_vp, C.c_int]),
     "phovo_engine_level_uses_wide": (C.c_int, [_vp, C.c_int, C.c_int]),
     "phovo_host_register": (C.c_int, [_vp, C.c_size_t]),

@@ -207,9 +207,16 @@ class AlignmentEngine:
         check(self._lib.phovo_engine_set_wide_policy(self._h, int(policy)), "phovo_engine_set_wide_policy")
 
     def set_iteration_cap(self, cap):
-        """Shipped thresholds, large batches: pairs still running after `cap` iterations of a level are finished by a
-        second launch (default 4; 0 = one launch).  Results are bit-identical either way."""
+        """Shipped thresholds: pairs still running after `cap` iterations of a level are finished by a second (and third)
+        launch (default 4; 0 = one launch).  Iteration counts are identical either way, poses agree within the parity
+        bar (the later launches use another geometry: last bits differ unless PHOVO_GN_TAIL_SAME_PLAN=1)."""
         check(self._lib.phovo_engine_set_iteration_cap(self._h, int(cap)), "phovo_engine_set_iteration_cap")
+
+    def set_batch_invariant(self, on=True):
+        """Every batch, whatever its size, takes the same kernels and geometries: a pair's result does not depend on how
+        many other pairs are aligned with it (what the sequence drivers set, so that a sequence cut into shards of any
+        sizes gives bit-identical poses)."""
+        check(self._lib.phovo_engine_set_batch_invariant(self._h, int(bool(on))), "phovo_engine_set_batch_invariant")
 
     def set_slide_policy(self, policy):
         """0 automatic (sliding-window kernel on levels whose owner map exceeds LDS), -1 exact kernel only."""

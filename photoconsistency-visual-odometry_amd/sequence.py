@@ -122,9 +122,10 @@ def chain_and_format(states, timestamps):
     return "\n".join(lines) + "\n"
 
 
-def align_shard(config_file, rgb, depth, pair_start, pair_stop, device_index, log=None):
+def align_shard(config_file, rgb, depth, pair_start, pair_stop, device_index, log=None, want_reports=False):
     """Decode, upload and align the pairs [pair_start, pair_stop) of the sequence on one GPU.  Pair t is
-    (frame t -> frame t+1).  Returns ([p, 6] states, frames decoded)."""
+    (frame t -> frame t+1).  Returns ([p, 6] states, frames decoded) -- with want_reports ([p, 6] states, frames
+    decoded, per-pair reports)."""
     f0, f1 = distributed.frames_needed(pair_start, pair_stop)
     n_pairs = pair_stop - pair_start
     if n_pairs <= 0:
@@ -144,10 +145,14 @@ def align_shard(config_file, rgb, depth, pair_start, pair_stop, device_index, lo
         log(f"decoded frames [{f0}, {f1}) for pairs [{pair_start}, {pair_stop})")
     with odometry.AlignmentEngine(device_index) as eng:
         eng.read_configuration_file(config_file)
+        eng.set_batch_invariant(True)        # a pair's pose must not depend on the size of the shard it falls into
         eng.set_intrinsic_matrix(K_TUM)
         eng.reserve_frames(f1 - f0, w, h)
         eng.upload_frames(0, np.stack(gray), np.stack(d16), depth_scale=DEPTH_SCALE)
         local = list(range(n_pairs))
+        if want_reports:
+            states, reports = eng.align_pairs(local, [i + 1 for i in local], want_reports=True)
+            return states, f1 - f0, list(reports)
         states = eng.align_pairs(local, [i + 1 for i in local])
     return states, f1 - f0
 
@@ -161,6 +166,9 @@ def run(config_file, dataset_dir, trajectory_path, backend=None, log=None):
     device = None
     dist = None
     if world > 1:
+        # whatever launcher started this rank: the host driver only does dmabuf IPC (RCCL needs it), set before torch loads
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("OMP_NUM_THREADS", "1")
         import torch
         import torch.distributed as dist
         backend = backend or os.environ.get("PHOVO_SEQUENCE_BACKEND", "nccl")

@@ -33,12 +33,22 @@ CASES = [
     dict(name="case_c", seed=2, w=128, h=96, holes=0.02, num_levels=4,
          max_iter=[0, 0, 6, 10], min_grad=[0.5, 0.5, 25.0, 14.0], lam=[1, 1, 1, 1],
          init=[0.004, -0.003, 0.002, 0.002, -0.001, 0.0015], min_depth=0.5, max_depth=2.2),
+    # the layered desk-like scene (synthetic.LayeredScene through sensor_like): depth discontinuities, occlusion (sources
+    # of different layers on one target), 20 % invalid REGIONS, Kinect-style depth noise; a larger motion than the others
+    dict(name="case_d", seed=11, w=160, h=120, scene="layered", trans=0.06, rot=0.02, num_levels=3,
+         max_iter=[4, 8, 12], min_grad=[0.0, 6.0, 3.0], lam=[1, 1, 1]),
 ]
 
 
 def main():
+    only = sys.argv[1:]                  # python tests/golden/make_golden.py [case_x ...]: regenerate just those
     for c in CASES:
-        p = synthetic.make_pair(c["seed"], c["w"], c["h"], holes=c["holes"])
+        if only and c["name"] not in only:
+            continue
+        if c.get("scene", "plane") == "layered":
+            p = synthetic.make_pair(c["seed"], c["w"], c["h"], scene="layered", trans=c["trans"], rot=c["rot"])
+        else:
+            p = synthetic.make_pair(c["seed"], c["w"], c["h"], holes=c["holes"])
         nl = c["num_levels"]
         gs = [0.0625] * nl
         pyr = twin.build_pyramids(p["gray0"], p["depth0"], p["gray1"], nl, gs)
@@ -70,6 +80,9 @@ def main():
         np.savez_compressed(path, **out)
         print(c["name"], "iters", iters, "executed", len(trace), "state", state,
               "bytes", os.path.getsize(path))
+        for l in range(nl - 1, -1, -1):
+            if c["max_iter"][l] > 0:
+                print("   level", l, twin.scatter_statistics(pyr[l], l, p["K"], state, cfg["min_depth"], cfg["max_depth"]))
 
 
 if __name__ == "__main__":

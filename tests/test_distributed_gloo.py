@@ -57,16 +57,25 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("n_pairs", [9, 16])       # uneven and even shards
-def test_two_ranks_gather_equals_single_process(tmp_path, n_pairs):
+@pytest.mark.parametrize("world,n_pairs", [(2, 9), (2, 16),      # uneven and even shards
+                                            (8, 601),            # the node: 601 pairs -> one shard of 76, seven of 75
+                                            (8, 5)])             # fewer pairs than ranks: three ranks hold nothing
+def test_ranks_gather_equals_single_process(tmp_path, world, n_pairs):
+    """World sizes 2 and 8 (the node the driver's scaling run uses): shard arithmetic, the padded all_gather_into_tensor of
+    uneven shards -- empty ones included -- and the pose chain, on every rank, against the single-process result."""
     import torch.multiprocessing as mp
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, n_pairs, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, n_pairs, str(tmp_path)), nprocs=world, join=True)
     ref = _states(n_pairs)
     ref_traj = distributed.trajectory_from_states(ref)
-    for r in range(2):
+    for r in range(world):
         np.testing.assert_array_equal(np.load(tmp_path / f"full_{r}.npy"), ref)
         np.testing.assert_array_equal(np.load(tmp_path / f"traj_{r}.npy"), ref_traj)
+    sizes = [distributed.shard_range(n_pairs, world, r) for r in range(world)]
+    assert sum(b - a for a, b in sizes) == n_pairs
+    if (world, n_pairs) == (8, 601):
+        assert [b - a for a, b in sizes] == [76] + [75] * 7
+        assert distributed.frames_needed(*sizes[7]) == (526, 602)      # the last rank needs frames 526 .. 601
 
 
 def test_trajectory_chain_and_tum_format():

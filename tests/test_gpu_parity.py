@@ -595,7 +595,8 @@ def test_batched_upload_equals_per_frame_upload():
 def test_upload_from_page_locked_caller_memory_and_many_chunks():
     """phovo_host_register (hipHostRegister behind the C ABI) + a batched upload of 150 frames = five staging chunks through
     the double-buffered path (copy stream beside the engine's stream): planes bit-identical to frame-by-frame uploads,
-    level-0 blur included; null arguments are refused."""
+    level-0 blur included; registering a range twice (or one that overlaps it) and unregistering an unknown pointer are
+    refused by the library's own bookkeeping, whatever the runtime underneath would say."""
     F, w, h = 150, 160, 120
     rs = np.random.RandomState(3)
     gray = rs.randint(0, 256, size=(F, h, w)).astype(np.uint8)
@@ -604,6 +605,10 @@ def test_upload_from_page_locked_caller_memory_and_many_chunks():
     L = native.lib()
     assert L.phovo_host_register(gray.ctypes.data, gray.nbytes) == 0
     assert L.phovo_host_register(d16.ctypes.data, d16.nbytes) == 0
+    assert L.phovo_host_register(gray.ctypes.data, gray.nbytes) == native.E_INVALID_ARGUMENT          # already registered
+    assert L.phovo_host_register(gray.ctypes.data + 4096, 8192) == native.E_INVALID_ARGUMENT          # inside a registered range
+    assert b"overlaps" in L.phovo_last_error()
+    assert L.phovo_host_unregister(gray.ctypes.data + 4096) == native.E_INVALID_ARGUMENT              # not the start of one
     assert L.phovo_host_register(None, 16) != 0
     try:
         with odometry.AlignmentEngine() as a, odometry.AlignmentEngine() as b:
@@ -620,6 +625,9 @@ def test_upload_from_page_locked_caller_memory_and_many_chunks():
     finally:
         assert L.phovo_host_unregister(gray.ctypes.data) == 0
         assert L.phovo_host_unregister(d16.ctypes.data) == 0
+    assert L.phovo_host_unregister(gray.ctypes.data) == native.E_INVALID_ARGUMENT                      # no longer registered
+    assert L.phovo_host_register(gray.ctypes.data, gray.nbytes) == 0                                   # and free to be registered again
+    assert L.phovo_host_unregister(gray.ctypes.data) == 0
 
 
 @pytest.mark.parametrize("size,expect", [

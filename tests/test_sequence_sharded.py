@@ -150,6 +150,23 @@ def test_two_gloo_ranks_decode_only_their_shard_then_stop_at_the_device_check(tm
     assert not out.exists()
 
 
+def test_eight_gloo_ranks_decode_their_shards_then_stop_at_the_device_check(tmp_path):
+    """World size 8 -- the node the driver's scaling run uses -- rehearsed on the CPU up to the device check: 33 frames =
+    32 pairs, four per rank, every rank decodes the five frames of its shard and then fails loudly (no CPU path)."""
+    if native.lib().phovo_device_count() > 0:
+        pytest.skip("a GPU is present: covered by the gpu-marked tests below")
+    write_tum_sequence(str(tmp_path / "seq"), 33, 64, 48)
+    out = tmp_path / "traj.txt"
+    r = subprocess.run([sys.executable, SHARDED, CFG5, str(tmp_path / "seq"), str(out), "--ranks", "8", "--backend", "gloo"],
+                       capture_output=True, text=True, timeout=900, env=_clean_env())
+    assert "starting 8 ranks" in r.stderr
+    for rank in range(8):
+        assert f"rank {rank}/8 joined the gloo group" in r.stderr
+        assert f"rank {rank}/8 decoded frames [{4 * rank}, {4 * rank + 5}) for pairs [{4 * rank}, {4 * rank + 4})" in r.stderr
+    assert r.returncode != 0 and "no HIP device available" in r.stderr
+    assert not out.exists()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # GPU: the whole path on a sequence of BASELINE config 3's length
 # ---------------------------------------------------------------------------------------------------------------
@@ -191,3 +208,78 @@ def test_sharded_sequence_is_byte_identical_to_the_single_process_app(tmp_path):
     # the poses are real: consecutive frames of the generator are a few centimetres apart
     last = [float(v) for v in want.decode().strip().split("\n")[-1].split()]
     assert np.isfinite(last).all() and abs(np.linalg.norm(last[4:8]) - 1.0) < 1e-9
+
+
+@pytest.mark.gpu
+def test_601_frames_against_the_oracle(tmp_path):
+    """BASELINE configs[2] at its named length against the ORACLE (not only the app against the sharded driver): the 601
+    frames are 40 renders cycled forwards and backwards, i.e. 78 distinct (source, target) pairs; the oracle aligns each
+    distinct pair once from the decoded PNGs (u16 depth * 1/5000, ...VisualOdometry.cpp:163) and all 600 device poses
+    are held to it -- identical iteration counts, ||log(T_gpu^-1 T_cpu)|| < 1e-9 per pair -- and so is the chained
+    600-pose trajectory (absolute trajectory error against the oracle's chain < 1e-9 m)."""
+    from oracle import oracle
+    seq = tmp_path / "seq"
+    write_tum_sequence(str(seq), 601, distinct=40, extra_depth_lines=2)
+    rgb, depth = sequence.read_sequence_lists(str(seq))
+    assert len(rgb) == 601
+    states, decoded, reports = sequence.align_shard(CFG5, rgb, depth, 0, 600, 0, want_reports=True)
+    assert decoded == 601 and states.shape == (600, 6)
+    n = native.read_config_file(CFG5)
+    nl = n.num_levels
+    ocfg = oracle.make_config(num_levels=nl, max_iter=list(n.max_num_iterations[:nl]), min_grad=list(n.min_gradient_norm[:nl]))
+    period = 2 * 40 - 2
+    which = [f % period if f % period < 40 else period - f % period for f in range(601)]
+    frames, expect = {}, {}
+    worst, oracle_states = 0.0, np.zeros((600, 6))
+    for t in range(600):
+        key = (which[t], which[t + 1])
+        if key not in expect:
+            for f, k in ((t, key[0]), (t + 1, key[1])):
+                if k not in frames:
+                    frames[k] = (sequence.read_gray8(rgb[f][1]),
+                                 sequence.read_depth16(depth[f][1]).astype(np.float64) * sequence.DEPTH_SCALE)
+            expect[key] = oracle.align_frames(ocfg, sequence.K_TUM, frames[key[0]][0], frames[key[0]][1], frames[key[1]][0])
+        es, eits = expect[key]
+        assert list(reports[t].iterations[:nl]) == eits, (t, key, list(reports[t].iterations[:nl]), eits)
+        assert reports[t].flags == 0
+        d = se3.state_distance(states[t], es)
+        worst = max(worst, d)
+        assert d < 1e-9, (t, key, d)
+        oracle_states[t] = es
+    assert len(expect) == 78
+    gpu_traj = distributed.trajectory_from_states(states)
+    cpu_traj = distributed.trajectory_from_states(oracle_states)
+    ate = float(np.max(np.linalg.norm(gpu_traj[:, :3, 3] - cpu_traj[:, :3, 3], axis=1)))
+    rot = float(np.max(np.abs(gpu_traj[:, :3, :3] - cpu_traj[:, :3, :3])))
+    assert ate < 1e-9 and rot < 1e-9, (ate, rot)
+    print(f"601 frames: 78 distinct pairs against the oracle, worst pose distance {worst:.3e}, trajectory error {ate:.3e} m")
+
+
+@pytest.mark.gpu
+def test_short_sequence_in_small_shards_is_byte_identical(tmp_path):
+    """The 8-GPU node on a SHORT sequence: 101 frames = 100 pairs give shards of 12-13 pairs (the automatic wide form's
+    range) and, with 13 shards, of 7-8 pairs (the latency geometry's).  The sequence drivers pin the engine's batch-
+    invariant mode, so every cut writes the same bytes: the C++ app in one process with 1, 8 and 13 shards (one engine
+    and one host thread each, sharing this box's GPU), and the one-process-per-GPU driver with 1 and 4 gloo ranks (the box
+    allows six processes on its card, this test process being one of them; eight RANKS are rehearsed on the CPU up to
+    the device check)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "apps")])
+    seq = tmp_path / "seq"
+    write_tum_sequence(str(seq), 101, distinct=30)
+    ref = tmp_path / "ref.txt"
+    r = subprocess.run([APP, CFG5, str(seq), str(ref), "--batch"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    want = ref.read_bytes()
+    assert want.count(b"\n") == 2 + 100
+    for n in (8, 13):
+        out = tmp_path / f"threads_{n}.txt"
+        r = subprocess.run([APP, CFG5, str(seq), str(out), "--batch", "--gpus", str(n)], capture_output=True, text=True,
+                           timeout=900, env=_clean_env({"PHOVO_VO_SHARE_DEVICES": "1"}))
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert out.read_bytes() == want, n
+    for ranks in (4, 1):
+        out = tmp_path / f"sharded_{ranks}.txt"
+        r = subprocess.run([sys.executable, SHARDED, CFG5, str(seq), str(out), "--ranks", str(ranks), "--backend", "gloo"],
+                           capture_output=True, text=True, timeout=900, env=_clean_env())
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert out.read_bytes() == want, ranks

@@ -8,11 +8,14 @@ def line(text, tag=""):
     lv = [(l["level"], round(l["avg_launch_ms"], 3), round(l["achieved_GBs"]), l["threads"], l["lds_bytes"])
           for l in d["roofline"]["levels"]]
     rt = d.get("reference_termination") or {}
-    print(tag, round(d["value"]), round(d["ms_per_step"], 3), "frac", round(d["roofline"]["frac"], 3), lv,
+    print(tag, round(d["value"]), round(d["ms_per_step"], 3), "frac", round(d["roofline"]["frac"], 3),
+          "all", round(d["roofline"]["all_levels_frac"], 3), lv, "its", [round(v, 2) for v in d["iterations_per_pair"]],
           "ref-term", round(rt.get("value", 0)))
 
 
-if len(sys.argv) > 1:
+if len(sys.argv) == 3 and not sys.argv[2].endswith(".json"):      # file, tag
+    line(open(sys.argv[1]).read(), sys.argv[2])
+elif len(sys.argv) > 1:
     for f in sys.argv[1:]:
         line(open(f).read(), f)
 else:
