@@ -55,6 +55,11 @@ typedef enum phovo_status {
 
 /* The per-level parameter vectors of the reference (...Analytic.h:91-103), as filled by
  * ReadConfigurationFile (:581-607) or by the constructor defaults (:430-443). */
+#define PHOVO_PAIR_RANK_DEFICIENT 4u  /* fewer than six Jacobian rows were filled in the last iteration of some level
+                                    (phovo_pair_report.valid_pixels): J^T J is singular by construction and the step taken
+                                    from it is rounding noise -- finite or not -- exactly as in the reference, which
+                                    inverts such a matrix without a word (...Analytic.h:540).                        */
+
 typedef struct phovo_config {
   int    num_levels;                                       /* numOptimizationLevels                      */
   int    blur_filter_size[PHOVO_MAX_LEVELS];               /* blurFilterSize (at each level)             */
@@ -62,7 +67,11 @@ typedef struct phovo_config {
   double lambda_optimization_step[PHOVO_MAX_LEVELS];       /* lambda_optimization_step (at each level)   */
   int    max_num_iterations[PHOVO_MAX_LEVELS];             /* max_num_iterations (at each level)         */
   double min_gradient_norm[PHOVO_MAX_LEVELS];              /* min_gradient_norm (at each level)          */
-  int    visualize_iterations;                             /* visualizeIterations (headless: ignored)    */
+  int    visualize_iterations;                             /* visualizeIterations: the reference shows |I1 - warped|
+                                                              in a window after every iteration (:551-557); here
+                                                              phovo_odometry_optimize writes that image to
+                                                              $PHOVO_VISUALIZE_DIR/optimize_imgDiff_level<L>_iteration<N>.pgm
+                                                              when the variable is set, and ignores the key otherwise */
 } phovo_config;
 
 /* What Optimize() did for one pair (the reference only prints this behind
@@ -204,10 +213,11 @@ int phovo_engine_set_depth_range(phovo_engine *e, double min_depth, double max_d
 int phovo_engine_set_build_all_levels(phovo_engine *e, int on);
 
 /* How a level is run.  The persistent form gives every pair ONE workgroup for all iterations of a level (the
- * throughput form).  The wide form cuts a pair into tiles of 1024 pixels, one workgroup each, with three launches
+ * throughput form).  The wide form cuts a pair into tiles of 1024 pixels, one workgroup each, with two launches
  * per iteration and a host look at the "done" words every 8 iterations (the latency form for a handful of pairs on
  * a large level; reference-exact configuration only).  policy: 0 = automatic (wide iff n_pairs <= 32 and the level
- * has >= 16384 pixels), 1 = wide wherever possible, -1 = never.  Results are the same either way. */
+ * has >= 16384 pixels; never with phovo_engine_set_batch_invariant), 1 = wide wherever possible, -1 = never.  Same
+ * iteration counts and poses within the parity bar either way (the forms sum in different orders). */
 int phovo_engine_set_wide_policy(phovo_engine *e, int policy);
 /* Levels whose owner map exceeds LDS (more than ~39 k pixels) run the sliding-window kernel (owner ring in LDS) followed
  * by the exact kernel (owner map in HBM) for the pairs whose warp left the window.  policy: 0 = automatic (that), -1 =

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -54,6 +55,9 @@ struct phovo_engine {
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr;           // batched uploads: host-to-device copies of chunk i+1 run beside the pyramid kernels of chunk i
   hipEvent_t ev_copied[2] = {}, ev_built[2] = {};     // per staging half
+  hipStream_t tail_stream = nullptr;           // the follow-up launches of a capped level, beside the next level's first launch
+  hipEvent_t ev_firsts[PHOVO_MAX_LEVELS] = {}, ev_tails[PHOVO_MAX_LEVELS] = {};   // per level: first launch(es) done / follow-ups done
+  hipEvent_t ev_total_start = nullptr, ev_total_stop = nullptr;
   hipEvent_t ev_start[PHOVO_MAX_LEVELS] = {};
   hipEvent_t ev_stop[PHOVO_MAX_LEVELS] = {};
   bool level_launched[PHOVO_MAX_LEVELS] = {};
@@ -98,6 +102,10 @@ struct phovo_engine {
   int slide_policy = 0;                        // 0 automatic (where the owner map exceeds LDS), -1 never
   int tail_stages = 3;                         // launches of a capped level: 3 = caps at iter_cap and 3 x iter_cap (PHOVO_GN_TAIL_STAGES=2: one cap)
   bool tail_same_plan = false;                 // PHOVO_GN_TAIL_SAME_PLAN=1: second launch with the first one's geometry (A/B, tests)
+  bool overlap_levels = true;                  // PHOVO_GN_OVERLAP=0: every launch of an enqueue on ONE stream (A/B, tests)
+  int *d_marks = nullptr;                      // [PHOVO_MAX_LEVELS][pairs] "handed over by the level's first launch" (view into d_pairs)
+  int tail_mid_plan = 0;                       // PHOVO_GN_TAIL_MID_PLAN, bit 0: the middle launch of a three-launch level takes the first launch's
+                                               // geometry instead of the latency geometry; bit 1: so does the second launch of a two-launch level
   int iter_cap = 4;                            // shipped thresholds, more pairs than workgroup slots: pairs still running after this
                                                // many iterations of a level are finished by a second launch (0 = off)
   int cu_count = 256;
@@ -176,9 +184,10 @@ bool use_wide_level(const phovo_engine *e, int n_pairs, int n_pixels)
   return n_pairs * 8 <= 256 && n_pixels >= 16384;
 }
 
+constexpr int HEAD_SETS = 4;
 // Byte offsets of the per-launch pair data for n pairs (see phovo_engine::d_pairs); every section starts 8-byte aligned.
 struct PairLayout {
-  size_t src, tgt, states, reports, heads, handover, handover_stride, total;
+  size_t src, tgt, states, reports, heads, handover, handover_stride, marks, marks_stride, total;
 };
 PairLayout pair_layout(int n_pairs)
 {
@@ -189,10 +198,12 @@ PairLayout pair_layout(int n_pairs)
   l.states = l.tgt + sizeof(int) * n2;
   l.reports = l.states + sizeof(double) * 6 * (size_t)n_pairs;
   l.heads = l.reports + sizeof(phovo_pair_report) * (size_t)n_pairs;
-  // three sets of heads per level: every launch of a level (up to three, see enqueue) drains its own queue
-  l.handover = l.heads + sizeof(int) * 3 * PHOVO_MAX_LEVELS * QUEUES_PER_LEVEL;
+  // four sets of heads per level: every launch of a level (up to four, see enqueue) drains its own queue
+  l.handover = l.heads + sizeof(int) * HEAD_SETS * PHOVO_MAX_LEVELS * QUEUES_PER_LEVEL;
   l.handover_stride = n2 + 2;                   // ints per level: the list of handed-over pairs and, at [n_pairs], its length
-  l.total = l.handover + sizeof(int) * l.handover_stride * 2 * PHOVO_MAX_LEVELS;       // two lists per level
+  l.marks = l.handover + sizeof(int) * l.handover_stride * 2 * PHOVO_MAX_LEVELS;       // two lists per level
+  l.marks_stride = n2;                          // ints per level: 1 = handed over by the level's first launch
+  l.total = l.marks + sizeof(int) * l.marks_stride * PHOVO_MAX_LEVELS;
   return l;
 }
 
@@ -427,6 +438,13 @@ int phovo_engine_create(int device, phovo_engine **out)
   phovo_extensions_default(&e->ext);
   hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
   if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking);
+  if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->tail_stream, hipStreamNonBlocking);
+  if (he == hipSuccess) he = hipEventCreate(&e->ev_total_start);
+  if (he == hipSuccess) he = hipEventCreate(&e->ev_total_stop);
+  for (int l = 0; l < PHOVO_MAX_LEVELS && he == hipSuccess; l++) {
+    he = hipEventCreateWithFlags(&e->ev_firsts[l], hipEventDisableTiming);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_tails[l], hipEventDisableTiming);
+  }
   for (int i = 0; i < 2 && he == hipSuccess; i++) {
     he = hipEventCreateWithFlags(&e->ev_copied[i], hipEventDisableTiming);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_built[i], hipEventDisableTiming);
@@ -442,6 +460,8 @@ int phovo_engine_create(int device, phovo_engine **out)
   e->slide_policy = std::getenv("PHOVO_GN_NO_SLIDE") ? -1 : 0;        // A/B switches for tools/
   e->tail_same_plan = std::getenv("PHOVO_GN_TAIL_SAME_PLAN") != nullptr;
   if (const char *st = std::getenv("PHOVO_GN_TAIL_STAGES")) e->tail_stages = std::atoi(st);
+  if (const char *st = std::getenv("PHOVO_GN_TAIL_MID_PLAN")) e->tail_mid_plan = std::atoi(st);
+  if (const char *st = std::getenv("PHOVO_GN_OVERLAP")) e->overlap_levels = std::atoi(st) != 0;
   if (const char *cap = std::getenv("PHOVO_GN_ITER_CAP")) e->iter_cap = std::atoi(cap) > 0 ? std::atoi(cap) : 0;
   if (he == hipSuccess) {
     int cus = 0;
@@ -460,6 +480,7 @@ int phovo_engine_destroy(phovo_engine *e)
   if (!e) return PHOVO_OK;
   (void)hipSetDevice(e->device);
   if (e->copy_stream) (void)hipStreamSynchronize(e->copy_stream);
+  if (e->tail_stream) (void)hipStreamSynchronize(e->tail_stream);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   free_pool(e);
   free_pairs(e);
@@ -471,7 +492,14 @@ int phovo_engine_destroy(phovo_engine *e)
     if (e->ev_copied[i]) (void)hipEventDestroy(e->ev_copied[i]);
     if (e->ev_built[i]) (void)hipEventDestroy(e->ev_built[i]);
   }
+  for (int l = 0; l < PHOVO_MAX_LEVELS; l++) {
+    if (e->ev_firsts[l]) (void)hipEventDestroy(e->ev_firsts[l]);
+    if (e->ev_tails[l]) (void)hipEventDestroy(e->ev_tails[l]);
+  }
+  if (e->ev_total_start) (void)hipEventDestroy(e->ev_total_start);
+  if (e->ev_total_stop) (void)hipEventDestroy(e->ev_total_stop);
   if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+  if (e->tail_stream) (void)hipStreamDestroy(e->tail_stream);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return PHOVO_OK;
@@ -973,6 +1001,7 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
   e->d_reports = reinterpret_cast<phovo_pair_report *>(e->d_pairs + pl.reports);
   e->d_work_counters = reinterpret_cast<int *>(e->d_pairs + pl.heads);
   e->d_handover = reinterpret_cast<int *>(e->d_pairs + pl.handover);
+  e->d_marks = reinterpret_cast<int *>(e->d_pairs + pl.marks);
   std::memset(e->h_up, 0, pl.reports);
   std::memcpy(e->h_up + pl.src, source_frames, sizeof(int) * (size_t)n_pairs);
   std::memcpy(e->h_up + pl.tgt, target_frames, sizeof(int) * (size_t)n_pairs);
@@ -981,6 +1010,35 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
   // one copy in (pair list + initial states, zeros without them), one memset (reports + the work-queue heads of all levels)
   PHOVO_HIP_CHECK(hipMemcpyAsync(e->d_pairs, e->h_up, pl.reports, hipMemcpyHostToDevice, e->stream));
   PHOVO_HIP_CHECK(hipMemsetAsync(e->d_pairs + pl.reports, 0, pl.total - pl.reports, e->stream));
+  PHOVO_HIP_CHECK(hipEventRecord(e->ev_total_start, e->stream));
+
+  // Overlap of consecutive levels (shipped thresholds).  A capped level ends with one or two launches that hold a few
+  // per cent of the pairs -- the long ones -- and leave most CUs idle (80x60, 8192 pairs: 0.33 of 1.1 ms).  Pairs are
+  // independent, so those follow-up launches go to a SECOND stream while the next level's first launch, on the
+  // engine's stream, already takes every pair that is not waiting for them (the first launch of a level marks the
+  // pairs it hands over; the next level's draws pass marked pairs by); a second "first launch" of the next level then
+  // takes the marked pairs from the hand-over list once the follow-ups have finished.  Same kernels, same geometries,
+  // same arithmetic per pair as on one stream: only the order in time changes (PHOVO_GN_OVERLAP=0: A/B, tests).
+  struct Pending { bool on = false; const int *list = nullptr; const int *marks = nullptr; hipEvent_t done = nullptr; };
+  Pending pending;                         // the level before: follow-ups in flight on tail_stream
+  auto join_pending = [&]() -> hipError_t {            // nothing of this enqueue is in flight on tail_stream any more (for e->stream)
+    if (!pending.on) return hipSuccess;
+    pending.on = false;
+    return hipStreamWaitEvent(e->stream, pending.done, 0);
+  };
+  // the next level that will run, and whether its first launch can take part in an overlap (persistent kernel, owner map in LDS)
+  auto next_overlappable = [&](int l) {
+    for (int m = l - 1; m >= 0; m--) {
+      if (e->cfg.max_num_iterations[m] <= 0) continue;
+      const LevelPool &nx = e->levels[m];
+      if (e->ext.sampling == PHOVO_SAMPLING_BILINEAR) return false;
+      if (use_wide_level(e, n_pairs, nx.n) && !(e->ext.huber_delta[m] > 0.0)) return false;
+      const bool few_m = !e->batch_invariant && n_pairs <= LATENCY_PAIRS && nx.plan_few_ok &&
+                         nx.plan_few.owner_in_lds == nx.plan.owner_in_lds;
+      return (few_m ? nx.plan_few : nx.plan).owner_in_lds;
+    }
+    return false;
+  };
 
   for (int l = e->cfg.num_levels - 1; l >= 0; l--) {                                 // coarse to fine  :502-503
     if (e->cfg.max_num_iterations[l] <= 0) continue;                                 // :526 (nothing observable happens)
@@ -1010,9 +1068,11 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
     static const bool single_queue = std::getenv("PHOVO_QUEUE_SINGLE") != nullptr;
     a.n_queues = (!single_queue && n_pairs >= 8 * 64) ? QUEUES_PER_LEVEL : 1;
     PHOVO_HIP_CHECK(hipEventRecord(e->ev_start[l], e->stream));
-    if (e->ext.sampling == PHOVO_SAMPLING_BILINEAR)
+    if (e->ext.sampling == PHOVO_SAMPLING_BILINEAR) {
+      PHOVO_HIP_CHECK(join_pending());
       PHOVO_HIP_CHECK(gn_launch_level_bilinear(a, e->ext.plane_storage, e->ext.jacobian_corrected != 0, e->cu_count, e->stream));
-    else if (use_wide_level(e, n_pairs, lv.n) && !(e->ext.huber_delta[l] > 0.0)) {
+    } else if (use_wide_level(e, n_pairs, lv.n) && !(e->ext.huber_delta[l] > 0.0)) {
+      PHOVO_HIP_CHECK(join_pending());
       if (e->owner_tagged) {            // the wide form starts from -1 everywhere and leaves it so
         PHOVO_HIP_CHECK(fill_i32(e->d_owner, e->owner_capacity, -1, e->stream));
         e->owner_tagged = false;
@@ -1028,6 +1088,23 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
       int *list0 = e->d_handover + (size_t)(2 * l) * hstride, *list1 = list0 + hstride;
       int *heads1 = e->d_work_counters + (PHOVO_MAX_LEVELS + l) * QUEUES_PER_LEVEL;
       int *heads2 = e->d_work_counters + (2 * PHOVO_MAX_LEVELS + l) * QUEUES_PER_LEVEL;
+      int *heads3 = e->d_work_counters + (3 * PHOVO_MAX_LEVELS + l) * QUEUES_PER_LEVEL;
+      int *marks = e->d_marks + (size_t)l * pair_layout(n_pairs).marks_stride;
+      if (!pl.owner_in_lds) PHOVO_HIP_CHECK(join_pending());     // (only levels with the owner map in LDS take part in an overlap)
+      // The first launch of this level: all pairs -- or, while the level before still finishes its long pairs on the
+      // second stream, first the pairs that are not waiting for that and then, behind it, the ones that were.
+      auto first_launches = [&](GNLevelArgs f) -> hipError_t {
+        hipError_t he;
+        if (pending.on) f.skip_marks = pending.marks;
+        if ((he = gn_launch_level(f, pl, e->ext.plane_storage, e->cu_count, e->stream)) != hipSuccess) return he;
+        if (pending.on) {
+          f.skip_marks = nullptr; f.handover_in = pending.list; f.takeover_flag = 0;
+          f.work_counter = heads3; f.n_queues = 1;
+          if ((he = join_pending()) != hipSuccess) return he;
+          if ((he = gn_launch_level(f, pl, e->ext.plane_storage, e->cu_count, e->stream)) != hipSuccess) return he;
+        }
+        return hipSuccess;
+      };
       if (!pl.owner_in_lds && e->slide_policy >= 0) {
         // Owner map too large for LDS: the sliding-window kernel first (owner ring in LDS); pairs whose warp leaves its
         // window are put on the hand-over list and continued, from the iteration they had reached, by the exact kernel
@@ -1048,31 +1125,59 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
         // pairs were aligned with it (a sequence gives the same trajectory file, byte for byte, however it is cut into
         // shards: tests/test_sequence_sharded.py).
         a.handover_out = list0; a.iter_cap = e->iter_cap;
-        PHOVO_HIP_CHECK(gn_launch_level(a, pl, e->ext.plane_storage, e->cu_count, e->stream));
+        // the follow-ups of THIS level beside the next level's first launch?
+        const bool overlap = e->overlap_levels && next_overlappable(l);
+        if (overlap) a.mark_out = marks;
+        PHOVO_HIP_CHECK(first_launches(a));
+        a.mark_out = nullptr;
+        hipStream_t ts = e->stream;
+        if (overlap) {
+          ts = e->tail_stream;
+          PHOVO_HIP_CHECK(hipEventRecord(e->ev_firsts[l], e->stream));
+          PHOVO_HIP_CHECK(hipStreamWaitEvent(ts, e->ev_firsts[l], 0));
+        }
         const GNLaunchPlan &tail = (!e->tail_same_plan && lv.plan_tail_ok && lv.plan_tail.owner_in_lds) ? lv.plan_tail : pl;
+        // The launch right behind the first one still has MANY pairs (6 % of the batch in the bench: two per CU at 8192
+        // pairs): it keeps the first launch's geometry, several workgroups per CU, so that all of them start at once; the
+        // last launch has about one pair per CU and takes the geometry that runs one pair fastest.  (Which geometry a
+        // launch takes depends on the level only, never on the batch size: see batch_invariant.)
+        const GNLaunchPlan &mid = (e->tail_mid_plan & 1) ? pl : tail;
         a.takeover_flag = 0; a.n_queues = 1;
         const int cap2 = 3 * e->iter_cap;
         // (a third launch pays on the larger levels: 160x120, 8192 pairs 3.85 -> 3.63 ms; on 80x60 its fixed cost is
         // larger than what the better balance returns)
         if (e->tail_stages >= 3 && a.max_iter > cap2 && lv.n >= 16384) {
           a.handover_in = list0; a.handover_out = list1; a.iter_cap = cap2; a.work_counter = heads1;
-          PHOVO_HIP_CHECK(gn_launch_level(a, tail, e->ext.plane_storage, e->cu_count, e->stream));
+          PHOVO_HIP_CHECK(gn_launch_level(a, mid, e->ext.plane_storage, e->cu_count, ts));
           a.handover_in = list1; a.work_counter = heads2;
+          a.handover_out = nullptr; a.iter_cap = 0;
+          PHOVO_HIP_CHECK(gn_launch_level(a, tail, e->ext.plane_storage, e->cu_count, ts));
         } else {
+          // two launches: the second one is "the launch right behind the first" and the last at once
           a.handover_in = list0; a.work_counter = heads1;
+          a.handover_out = nullptr; a.iter_cap = 0;
+          PHOVO_HIP_CHECK(gn_launch_level(a, (e->tail_mid_plan & 2) ? pl : tail, e->ext.plane_storage, e->cu_count, ts));
         }
-        a.handover_out = nullptr; a.iter_cap = 0;
-        PHOVO_HIP_CHECK(gn_launch_level(a, tail, e->ext.plane_storage, e->cu_count, e->stream));
-        PHOVO_HIP_CHECK(hipEventRecord(e->ev_stop[l], e->stream));
+        PHOVO_HIP_CHECK(hipEventRecord(e->ev_stop[l], ts));       // (the level's span ends with its last follow-up, on whichever stream)
+        if (overlap) {
+          PHOVO_HIP_CHECK(hipEventRecord(e->ev_tails[l], ts));
+          pending.on = true; pending.list = list0; pending.marks = marks; pending.done = e->ev_tails[l];
+        }
         e->level_launched[l] = true;
         continue;
       }
-      PHOVO_HIP_CHECK(gn_launch_level(a, pl, e->ext.plane_storage, e->cu_count, e->stream));
-      if (!pl.owner_in_lds) e->owner_tagged = true;          // tagged entries stay behind (the kernel wipes per pair)
+      if (pl.owner_in_lds) {
+        PHOVO_HIP_CHECK(first_launches(a));                  // one launch (no cap on this level): all pairs, or the two halves
+      } else {
+        PHOVO_HIP_CHECK(gn_launch_level(a, pl, e->ext.plane_storage, e->cu_count, e->stream));
+        e->owner_tagged = true;                              // tagged entries stay behind (the kernel wipes per pair)
+      }
     }
     PHOVO_HIP_CHECK(hipEventRecord(e->ev_stop[l], e->stream));
     e->level_launched[l] = true;
   }
+  PHOVO_HIP_CHECK(join_pending());
+  PHOVO_HIP_CHECK(hipEventRecord(e->ev_total_stop, e->stream));
   e->have_timing = true;
   return PHOVO_OK;
 }
@@ -1129,7 +1234,7 @@ int phovo_engine_last_align_ms(const phovo_engine *e, double *total_ms, double l
   if (!e->have_timing) return fail(PHOVO_E_NOT_READY, "last_align_ms: nothing has been enqueued");
   PHOVO_HIP_CHECK(hipSetDevice(e->device));
   PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
-  double total = 0;
+  if (e->tail_stream) PHOVO_HIP_CHECK(hipStreamSynchronize(e->tail_stream));
   for (int l = 0; l < PHOVO_MAX_LEVELS; l++) {
     double ms = 0;
     if (e->level_launched[l]) {
@@ -1138,9 +1243,12 @@ int phovo_engine_last_align_ms(const phovo_engine *e, double *total_ms, double l
       ms = f;
     }
     if (level_ms) level_ms[l] = ms;
-    total += ms;
   }
-  if (total_ms) *total_ms = total;
+  if (total_ms) {           // first launch to last, once: the spans of consecutive levels may overlap (enqueue)
+    float f = 0;
+    PHOVO_HIP_CHECK(hipEventElapsedTime(&f, e->ev_total_start, e->ev_total_stop));
+    *total_ms = f;
+  }
   return PHOVO_OK;
 }
 
@@ -1297,11 +1405,104 @@ int phovo_odometry_set_initial_state_vector(phovo_odometry *o, const double stat
   return PHOVO_OK;
 }
 
+// visualizeIterations, headless (...Analytic.h:515-517,359-362,551-557).  The reference fills a warped source image
+// while it computes the residuals -- warped(tr, tc) = I0(r, c) for every source pixel that passes the depth gate and lands
+// in bounds, last raster writer wins, zero elsewhere -- and after every iteration that does NOT end the level shows
+// |I1 - warped| in a window and waits for a key.  Here, when the configuration asks for it AND PHOVO_VISUALIZE_DIR names a
+// directory, Optimize() runs one iteration per launch (same kernels, same arithmetic as the fused loop: the state a launch
+// ends with is the state the next one starts from) and writes that image as
+//   <dir>/optimize_imgDiff_level<L>_iteration<N>.pgm   (8 bit: |diff| * 255, rounded; what imshow does to a [0, 1] image)
+// Display code, on the host and outside every timed region; without the directory the key is parsed and ignored as before.
+static int write_iteration_image(phovo_engine *e, int level, int iteration, const double pre_state[6], const char *dir)
+{
+  const LevelPool &lv = e->levels[level];
+  std::vector<double> i0((size_t)lv.n), d0((size_t)lv.n), i1((size_t)lv.n), warped((size_t)lv.n, 0.0);
+  int st = phovo_engine_get_level_planes(e, 0, level, i0.data(), d0.data(), nullptr, nullptr);
+  if (st != PHOVO_OK) return st;
+  st = phovo_engine_get_level_planes(e, 1, level, i1.data(), nullptr, nullptr, nullptr);
+  if (st != PHOVO_OK) return st;
+  double rt[16];
+  phovo_eigen_pose(pre_state, rt);
+  const double sc = 1.0 / std::pow(2, level);
+  const double fx = e->K[0] * sc, fy = e->K[4] * sc, ox = e->K[2] * sc, oy = e->K[5] * sc;
+  const double ifx = 1.f / fx, ify = 1.f / fy;
+  for (int r = 0; r < lv.h; r++)
+    for (int c = 0; c < lv.w; c++) {
+      const double pz = d0[(size_t)r * lv.w + c];
+      if (!(e->min_depth < pz && pz < e->max_depth)) continue;                     // :280
+      const double px = (c - ox) * pz * ifx, py = (r - oy) * pz * ify;            // :282-283
+      const double X = ((rt[0] * px + rt[1] * py) + rt[2] * pz) + rt[3];           // :291
+      const double Y = ((rt[4] * px + rt[5] * py) + rt[6] * pz) + rt[7];
+      const double Z = ((rt[8] * px + rt[9] * py) + rt[10] * pz) + rt[11];
+      const double iz = 1.0 / Z;
+      const double rr = std::round((Y * fy) * iz + oy), rc = std::round((X * fx) * iz + ox);   // :294-298
+      if (rr >= 0 && rr < (double)lv.h && rc >= 0 && rc < (double)lv.w)            // :302-303
+        warped[(size_t)rr * lv.w + (size_t)rc] = i0[(size_t)r * lv.w + c];         // :361
+    }
+  std::vector<unsigned char> img((size_t)lv.n);
+  for (int k = 0; k < lv.n; k++) {
+    const double v = std::fabs(i1[(size_t)k] - warped[(size_t)k]) * 255.0;         // cv::absdiff  :554
+    img[(size_t)k] = (unsigned char)(v >= 255.0 ? 255 : (int)std::lrint(v));
+  }
+  const std::string path = std::string(dir) + "/optimize_imgDiff_level" + std::to_string(level) + "_iteration" +
+                           std::to_string(iteration) + ".pgm";
+  FILE *f = std::fopen(path.c_str(), "wb");
+  if (!f) return fail(PHOVO_E_IO, "visualizeIterations: cannot write " + path);
+  std::fprintf(f, "P5\n%d %d\n255\n", lv.w, lv.h);
+  const bool ok = std::fwrite(img.data(), 1, img.size(), f) == img.size();
+  std::fclose(f);
+  return ok ? PHOVO_OK : fail(PHOVO_E_IO, "visualizeIterations: short write to " + path);
+}
+
+static int optimize_visualized(phovo_odometry *o, const char *dir)
+{
+  phovo_engine *e = o->engine;
+  const phovo_config full = e->cfg;
+  const int src = 0, tgt = 1;
+  phovo_pair_report total{};
+  int st = PHOVO_OK;
+  for (int l = full.num_levels - 1; l >= 0 && st == PHOVO_OK; l--) {               // coarse to fine  :502-503
+    total.iterations[l] = 1;                                                       // a level without iterations still runs the loop once
+    if (full.max_num_iterations[l] <= 0) continue;
+    phovo_config one = full;
+    for (int m = 0; m < one.num_levels; m++) one.max_num_iterations[m] = m == l ? 1 : 0;
+    one.visualize_iterations = 0;
+    for (int it = 1;; it++) {
+      double pre[6];
+      std::memcpy(pre, o->state, sizeof(pre));
+      // (levels that stay resident keep the pool: only max_num_iterations changes)
+      e->cfg = one;
+      phovo_pair_report rep{};
+      st = phovo_engine_align_pairs(e, 1, &src, &tgt, o->state, o->state, &rep);
+      e->cfg = full;
+      if (st != PHOVO_OK) break;
+      total.iterations[l] = it;
+      total.gradient_norm = rep.gradient_norm;
+      total.flags |= rep.flags;
+      total.valid_pixels[l] = rep.valid_pixels[l];
+      const bool stop = it >= full.max_num_iterations[l] || rep.gradient_norm < full.min_gradient_norm[l] ||
+                        (rep.flags & PHOVO_PAIR_NONFINITE);                       // :383,388
+      if (stop) break;
+      st = write_iteration_image(e, l, it, pre, dir);                              // :551-557: only when the level goes on
+      if (st != PHOVO_OK) break;
+    }
+  }
+  e->cfg = full;
+  if (st != PHOVO_OK) return st;
+  o->report = total;
+  o->optimized = true;
+  return PHOVO_OK;
+}
+
 int phovo_odometry_optimize(phovo_odometry *o)
 {
   if (!o) return fail(PHOVO_E_INVALID_ARGUMENT, "Optimize: null");
   if (!o->have_source || !o->have_target)
     return fail(PHOVO_E_NOT_READY, "Optimize: SetSourceFrame and SetTargetFrame must be called first");
+  if (o->engine->cfg.visualize_iterations) {
+    const char *dir = std::getenv("PHOVO_VISUALIZE_DIR");
+    if (dir && *dir) return optimize_visualized(o, dir);
+  }
   const int src = 0, tgt = 1;
   // Like the reference, Optimize() starts from the CURRENT state vector (:539 updates m_StateVector in place).
   const int st = phovo_engine_align_pairs(o->engine, 1, &src, &tgt, o->state, o->state, &o->report);

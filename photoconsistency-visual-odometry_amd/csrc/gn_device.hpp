@@ -253,111 +253,17 @@ __device__ __forceinline__ int draw_pair(int *heads, int n_queues, int n_pairs)
 // queue.  n_pairs = nothing left.
 __device__ __forceinline__ int draw_pair_any(const GNLevelArgs &A)
 {
-  if (!A.handover_in) return draw_pair(A.work_counter, A.n_queues, A.n_pairs);
+  if (!A.handover_in) {
+    int p = draw_pair(A.work_counter, A.n_queues, A.n_pairs);
+    if (A.skip_marks) {              // (the queue heads only grow: the loop ends with a pair of this launch's or with n_pairs)
+      while (p < A.n_pairs && __hip_atomic_load(&A.skip_marks[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+        p = draw_pair(A.work_counter, A.n_queues, A.n_pairs);
+    }
+    return p;
+  }
   const int count = __hip_atomic_load(&A.handover_in[A.n_pairs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int i = atomicAdd(A.work_counter, 1);
   return i < count ? __hip_atomic_load(&A.handover_in[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : A.n_pairs;
-}
-
-// ---- look-ahead of the work loop (gn_level_kernel) ------------------------------------------------------------------
-// A pair used to cost its workgroup four DEPENDENT trips to HBM before the first pixel was touched -- ticket (atomic),
-// src / tgt index, state, first chunk -- about 19 us against 30 us per iteration (80x60), which is what kept the shipped
-// thresholds (3 iterations per pair and level on average) at 0.55 of the roofline.  Now the descriptor of the NEXT pair
-// is fetched while the current one iterates: during the first iteration's serial section (wave 0 solves, the others
-// would idle at the barrier) the last wave draws the next ticket, fetches the pair's state, frame indices and starting
-// iteration with ONE load (lane l fetches dword l of the block below) and stores them into LDS.  The block is read once,
-// in the next pair's prologue.
-enum { NX_STATE = 0 /* 6 doubles = 12 dwords */, NX_SRC = 12, NX_TGT = 13, NX_IT = 14, NX_PAIR = 15, NX_COUNT = 16 };
-
-// The pairs queue q of the 8-queue form serves: [first, first + size).
-__device__ __forceinline__ void queue_span(const GNLevelArgs &A, int q, int &first, int &size)
-{
-  const int per = (A.n_pairs + A.n_queues - 1) / A.n_queues;
-  first = q * per;
-  size = first >= A.n_pairs ? 0 : (first + per > A.n_pairs ? A.n_pairs - first : per);
-}
-
-// First half of a draw (one lane): the atomic goes out, nothing waits for it.  Returns what the atomic returns.
-__device__ __forceinline__ int draw_begin(const GNLevelArgs &A)
-{
-  if (A.handover_in || A.n_queues <= 1) return atomicAdd(A.work_counter, 1);
-  const int q = (int)(blockIdx.x & (unsigned)(A.n_queues - 1));
-  int first, size;
-  queue_span(A, q, first, size);
-  return size > 0 ? atomicAdd(A.work_counter + q, 1) : 0;        // (an empty queue: 0 >= size sends draw_end on)
-}
-
-// Second half (same lane): the pair the ticket t stands for, or n_pairs when nothing is left.  Same order of queues as
-// draw_pair; with handover_in the ticket indexes the list an earlier launch of the level left behind.
-__device__ __forceinline__ int draw_end(const GNLevelArgs &A, int t)
-{
-  if (A.handover_in) {
-    const int count = __hip_atomic_load(&A.handover_in[A.n_pairs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return t < count ? __hip_atomic_load(&A.handover_in[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : A.n_pairs;
-  }
-  if (A.n_queues <= 1) return t < A.n_pairs ? t : A.n_pairs;
-  int q = (int)(blockIdx.x & (unsigned)(A.n_queues - 1));
-  int first, size;
-  queue_span(A, q, first, size);
-  if (t < size) return first + t;
-  for (int tries = 1; tries < A.n_queues; tries++) {           // the caller's own queue is empty: the others in turn
-    q = (q + 1) & (A.n_queues - 1);
-    queue_span(A, q, first, size);
-    if (size > 0) {
-      const int t2 = atomicAdd(A.work_counter + q, 1);
-      if (t2 < size) return first + t2;
-    }
-  }
-  return A.n_pairs;
-}
-
-// Whole wave, `pair` wave-uniform: lane l fetches dword l of the pair's descriptor (state, frame indices, starting
-// iteration) -- ONE load instruction -- and lookahead_store puts it into the look-ahead block.  Nothing is fetched for
-// pair >= n_pairs (no address is formed from it).
-// (global_load_lds would need no register, but any LDS access behind a pending LDS-DMA makes the compiler drain the
-// vector-memory counter -- the pixel loops' own prefetches included: measured, -3 % on the whole alignment.)
-__device__ __forceinline__ int lookahead_load(const GNLevelArgs &A, int pair, int lane)
-{
-  int v = 0;
-  const int n_dwords = A.handover_in ? NX_IT + 1 : NX_IT;      // the starting iteration only exists for handed-over pairs
-  if (pair < A.n_pairs && lane < n_dwords) {
-    const char *g = reinterpret_cast<const char *>(A.states + (size_t)pair * 6) + 4 * lane;
-    if (lane == NX_SRC) g = reinterpret_cast<const char *>(A.src + pair);
-    if (lane == NX_TGT) g = reinterpret_cast<const char *>(A.tgt + pair);
-    if (lane == NX_IT) g = reinterpret_cast<const char *>(&A.reports[pair].iterations[A.level]);
-    v = *reinterpret_cast<const int *>(g);
-  }
-  return v;
-}
-__device__ __forceinline__ void lookahead_store(const GNLevelArgs &A, int pair, int desc, int lane, int *s_next)
-{
-  if (lane < NX_PAIR) s_next[lane] = desc;
-  if (lane == NX_PAIR) s_next[NX_PAIR] = pair < A.n_pairs ? pair : A.n_pairs;
-}
-
-// Workgroup barrier of the level kernel.  The plain form is the raw s_barrier behind an explicit LDS wait (which the
-// compiler is known to leave out, see the work loop) and NOTHING else: the kernel keeps loads in flight ACROSS its
-// barriers (the first chunks of the pass behind the barrier are requested in front of it), and the fence that
-// __syncthreads() carries may drain the vector-memory counter.  GLOBAL = true (owner map in HBM: waves of a workgroup exchange data through global atomics) keeps the
-// fenced form.  A one-wave workgroup needs neither.
-template <int NW, bool GLOBAL>
-__device__ __forceinline__ void wg_barrier()
-{
-  if constexpr (NW > 1) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#ifdef PHOVO_AB_SYNCTHREADS       // A/B diagnostic build only
-    if constexpr (true) {
-#else
-    if constexpr (GLOBAL) {
-#endif
-      __syncthreads();
-    } else {
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-    }
-  } else {
-    asm volatile("" ::: "memory");      // a wave is in step with itself and its LDS operations execute in order
-  }
 }
 
 // The calling thread puts `pair` on handover_out (after its state and iteration count have been stored; the kernel
@@ -366,6 +272,7 @@ __device__ __forceinline__ void handover_append(const GNLevelArgs &A, int pair)
 {
   const int slot = atomicAdd(&A.handover_out[A.n_pairs], 1);
   A.handover_out[slot] = pair;
+  if (A.mark_out) A.mark_out[pair] = 1;
 }
 
 // v_writelane_b32: lane `lane` (wave-uniform) of `old` becomes `value` (wave-uniform); the other lanes keep theirs.
@@ -461,6 +368,7 @@ __device__ __forceinline__ void reduce_solve_update(double (&acc)[NRED], int lan
       for (int i = 0; i < 6; i++) s_state[i] = st[i];
       s_ctl[CTL_DONE] = done ? 1 : 0;
       if (!finite) s_ctl[CTL_FLAGS] |= (int)PHOVO_PAIR_NONFINITE;
+      if (last_valid < 6) s_ctl[CTL_FLAGS] |= (int)PHOVO_PAIR_RANK_DEFICIENT;
     }
     last_gnorm = gnorm;
   }

@@ -55,8 +55,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
   double *s_state = s_cst + 32;                                        // [8]
   double *s_red = s_state + 8;                                         // [NW][NRED]
   int *s_ctl = reinterpret_cast<int *>(s_red + NW * NRED);             // [CTL_COUNT]
-  int *s_next = s_ctl + CTL_COUNT;                                     // [NX_COUNT] look-ahead block (gn_device.hpp)
-  unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(s_next + NX_COUNT);  // [n_chunks] (!MASK_REG)
+  unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(s_ctl + CTL_COUNT);  // [n_chunks] (!MASK_REG)
   unsigned char *p = reinterpret_cast<unsigned char *>(s_mask + (MASK_REG ? 0 : A.n_chunks));
   int *s_owner = reinterpret_cast<int *>(p);                           // [n] (OWNER_LDS) or [n_lds] (owner map in HBM)
   if (OWNER_LDS) p += sizeof(int) * ((A.n + 1) & ~1);
@@ -68,62 +67,36 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
   // wave-uniform by construction; saying so lets the chunk loops run on the scalar unit (s_cmp / s_cbranch)
   // instead of exec-masked vector compares
   const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
-  constexpr int PFW = NW - 1;       // the wave that looks ahead (not wave 0: that one has the serial section of every iteration)
-  constexpr bool GLOBAL_SYNC = !OWNER_LDS;    // waves exchange owner entries through HBM: barriers keep their fence
   const int n = A.n, W = A.w, H = A.h;
   // Work queue: the grid has as many workgroups as fit the chip; each draws pair after pair from an atomic counter.
   // Pairs stop after data-dependent iteration counts and the hardware deals blocks to the 8 XCDs round-robin, so a
   // one-block-per-pair grid leaves whole XCDs idle while another one still works through its long pairs.
-  // The descriptor of a pair (index, frames, state, starting iteration) reaches the workgroup through the look-ahead
-  // block in LDS, ONE PAIR AHEAD (gn_device.hpp): wave PFW draws the ticket and requests the descriptor during the
-  // first iteration of the pair before; for the very first pair it does so here.  (With handover_in the pairs come from
-  // the list an earlier launch of this level left behind.)
+  // Thread 0 draws the next index in the same block that writes the finished pair back, so that the only thing between
+  // the iteration loop and the barrier at the head of the work loop is one if-block (two adjacent `if (tid == 0)`
+  // blocks, one either side of the back edge, were threaded together by the compiler into a loop that reached that
+  // barrier with thread 0 parked: a hang).
+  // (draw_pair_any: with handover_in the pairs come from the list an earlier launch of this level left behind)
   // The owner map in LDS is wiped ONCE per workgroup: pass 2 resets every slot it reads, and it reads all of them.
   for (int k = tid; k < (OWNER_LDS ? n : n_lds); k += T) s_owner[k] = -1;
-  if (wave == PFW) {
-    int first_pair = 0;
-    if (lane == 0) first_pair = draw_end(A, draw_begin(A));
-    first_pair = __builtin_amdgcn_readfirstlane(first_pair);
-    lookahead_store(A, first_pair, lookahead_load(A, first_pair, lane), lane, s_next);
-  }
+  if (tid == 0) s_ctl[CTL_PAIR] = draw_pair_any(A);
   for (;;) {
-  // What the look-ahead wave has stored must have LEFT its LDS queue before any wave is released: the compiler omits
+  // The ticket thread 0 has just stored must have LEFT its LDS queue before any wave is released: the compiler omits
   // the wait in front of this one barrier (it relies on LDS operations being ordered across waves), and on the GPU
   // about one wave in 10^5 then read the previous ticket and aligned the wrong pair's pixels into this pair's sums --
   // or, on the last round, would never have left the loop.  Found by test_work_queue_results_do_not_depend_on_...
-  // (wg_barrier says the wait explicitly.)
-  wg_barrier<NW, GLOBAL_SYNC>();
-  const int pair = __builtin_amdgcn_readfirstlane(s_next[NX_PAIR]);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int pair = __builtin_amdgcn_readfirstlane(s_ctl[CTL_PAIR]);
   if (pair >= A.n_pairs) break;           // uniform: every wave of the workgroup leaves together
-  const int pair_src = __builtin_amdgcn_readfirstlane(s_next[NX_SRC]);
-  const int pair_tgt = __builtin_amdgcn_readfirstlane(s_next[NX_TGT]);
-  // continuing a pair an earlier launch handed over: its completed iterations count
-  const int it0 = A.handover_in ? __builtin_amdgcn_readfirstlane(s_next[NX_IT]) : 0;
 
-  const unsigned char *src_frame = A.planes + (size_t)pair_src * A.frame_bytes;
-  const unsigned char *tgt_frame = A.planes + (size_t)pair_tgt * A.frame_bytes;
+  const unsigned char *src_frame = A.planes + (size_t)A.src[pair] * A.frame_bytes;
+  const unsigned char *tgt_frame = A.planes + (size_t)A.tgt[pair] * A.frame_bytes;
   int *g_owner = OWNER_LDS ? nullptr : A.g_owner + (size_t)pair * (size_t)n;
   const __amdgpu_buffer_rsrc_t rI0 = plane_rsrc<TI>(src_frame + A.plane_off[PLANE_I], n);
   const __amdgpu_buffer_rsrc_t rD0 = plane_rsrc<TD>(src_frame + A.plane_off[PLANE_D], n);
   const __amdgpu_buffer_rsrc_t rI1 = plane_rsrc<TI>(tgt_frame + A.plane_off[PLANE_I], n);
   const __amdgpu_buffer_rsrc_t rGX = plane_rsrc<TI>(tgt_frame + A.plane_off[PLANE_GX], n);
   const __amdgpu_buffer_rsrc_t rGY = plane_rsrc<TI>(tgt_frame + A.plane_off[PLANE_GY], n);
-
-  // Pass 1 keeps PD depth chunks per wave in flight (a ring of PD registers).  One chunk ahead -- 1 KB per wave -- was
-  // enough while the planes come from the Infinity Cache, but the FIRST iteration of a pair reads them from HBM, where 16
-  // waves per CU with 1 KB each in flight are good for ~2 TB/s chip-wide (Little's law at ~2 us): with the shipped
-  // thresholds (3 iterations per pair on average) that first pass was a sixth of a pair's time.  The ring of the first
-  // iteration is requested HERE, in front of the prologue (pose constants, a barrier), and the ring of every later
-  // iteration right behind pass 2 of the one before, in front of the reduction and wave 0's solve: no pass starts on an
-  // empty pipeline.
-  constexpr int PD = 4;
-  double pzr[PD];
-#ifdef PHOVO_AB_PREISSUE
-  if constexpr (OWNER_LDS) {
-#pragma unroll
-    for (int i = 0; i < PD; i++) pzr[i] = plane_load<TD>(rD0, wave * WAVE + lane + i * NW * WAVE);   // past the plane: 0
-  }
-#endif
 
   // ---- level prologue -------------------------------------------------------------------
   if (!OWNER_LDS) {
@@ -139,7 +112,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
   if (wave == 0) {
     double st[6];
 #pragma unroll
-    for (int j = 0; j < 6; j++) st[j] = reinterpret_cast<const double *>(s_next + NX_STATE)[j];
+    for (int j = 0; j < 6; j++) st[j] = A.states[(size_t)pair * 6 + j];
     write_pose_constants(st[0], st[1], st[2], st[3], st[4], st[5], s_cst, lane);
     if (lane == 0) {
 #pragma unroll
@@ -148,7 +121,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
       s_ctl[CTL_FLAGS] = 0;
     }
   }
-  wg_barrier<NW, GLOBAL_SYNC>();
+  __syncthreads();
 
   const double fx = A.fx, fy = A.fy, ox = A.ox, oy = A.oy, ifx = A.ifx, ify = A.ify;
   const double min_d = A.min_depth, max_d = A.max_depth;
@@ -163,23 +136,13 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
   // A wave walks the image in chunks of 64 consecutive pixels, NW chunks apart; (row, column) of a
   // lane's pixel is carried along instead of divided out per pixel.
   const int k0 = wave * WAVE + lane;
+  const int r0 = k0 / W, c0 = k0 - r0 * W;
   const int step_r = (NW * WAVE) / W, step_c = (NW * WAVE) - step_r * W;
   const RowColStep rc_step = make_rowcol_step(step_r, step_c, W);
-  // (row, column) of the lane's first pixel, worked out at the head of EACH pass (five fp64 instructions) instead of
-  // once per pair: kept in registers across pass 2 -- which sits at the 128-register cap -- they were spilled, and their
-  // reloads in front of pass 1's loop made every wait inside that loop a wait for everything in flight.
-  // row = trunc((k + 0.5) / W): (k + 0.5) / W is at least 0.5 / W away from an integer, far more than the rounding of the
-  // product; column = k - row * W is exact.
-  const double inv_w = uniform_f64(1.0 / dW);
-  auto first_rowcol = [&](double &cd, double &rd) {
-    int kk = k0;
-    asm volatile("" : "+v"(kk));                  // (opaque: the compiler would hoist the result out of the iteration loop and spill it)
-    const double kd = (double)kk;
-    rd = trunc((kd + 0.5) * inv_w);
-    cd = fma(-rd, dW, kd);
-  };
+  const double cd0 = (double)c0, rd0 = (double)r0;
 
-  int iteration = it0;
+  int iteration = 0;                // continuing a pair an earlier launch handed over: its completed iterations count
+  if (A.handover_in) iteration = __builtin_amdgcn_readfirstlane(A.reports[pair].iterations[A.level]);
   bool handed_over = false;
   double last_gnorm = 0.0;
   int last_valid = 0;
@@ -222,22 +185,13 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
     // MASK_REG: chunk j's "landed in bounds" ballot lives in lane j of two registers (v_writelane here, v_readlane
     // + exec mask in pass 2): no per-lane shifting and masking in either pass
     int inb_lo = 0, inb_hi = 0;
-    int n_rows = 0;                 // Jacobian rows this wave fills in this iteration (scalar unit: popcount of the ballots)
+    int n_rows = 0;                 // Jacobian rows this wave fills in this iteration (!MASK_REG: popcount of the ballots as they come)
     {
       int k = k0, j = 0;
-      asm volatile("" : "+v"(k));                   // (opaque, like first_rowcol's: nothing derived from it leaves the iteration loop)
-      double cd, rd;
-      first_rowcol(cd, rd);
+      double cd = cd0, rd = rd0;
       // software prefetch: the depth of the NEXT chunk is requested before this chunk is processed, so
       // every wave keeps a load in flight while it computes (the passes are bound by bytes in flight per CU)
-      double pz_next = 0.0;
-      if constexpr (!OWNER_LDS) pz_next = plane_load<TD>(rD0, k);
-#ifndef PHOVO_AB_PREISSUE       // A/B diagnostic build only: the ring is filled here, at the head of the pass
-      if constexpr (OWNER_LDS) {
-#pragma unroll
-        for (int i = 0; i < PD; i++) pzr[i] = plane_load<TD>(rD0, k + i * NW * WAVE);
-      }
-#endif
+      double pz_next = plane_load<TD>(rD0, k);
       // the translation sits in vector registers during this pass (pass 1 has registers to spare): an fma takes one
       // scalar operand, and the rotation entry already is one
       double cxv = cx, cyv = cyy, czv = cz;
@@ -270,9 +224,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
         t_out = (int)fma(rr, dW, rc);                                     // exact in fp64: one fma + one conversion
       };
       auto keep_mask = [&](const unsigned long long m, const int chunk) {
-#ifndef PHOVO_AB_NO_ROWS
-        n_rows += __builtin_popcountll(m);
-#endif
+        if (!MASK_REG) n_rows += __builtin_popcountll(m);
         if (MASK_REG) {
           inb_lo = writelane_b32(inb_lo, (int)(unsigned)m, j);
           inb_hi = writelane_b32(inb_hi, (int)(unsigned)(m >> 32), j);
@@ -281,63 +233,26 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
         }
       };
       if constexpr (OWNER_LDS) {
-        auto chunk_body = [&](const int chunk, double &slot) {
+        auto chunk_body = [&](const int chunk) {
+          const double pz = pz_next;                                      // :279
+          pz_next = plane_load<TD>(rD0, k + NW * WAVE);                   // past the plane: 0
           unsigned long long m;
           int t;
-          warp_chunk(slot, m, t);                                         // :279
-          // The slot is refilled BEHIND the last use of its value, into the same register: requested in front of it the
-          // new value needs a second register and a copy at the loop's back edge -- which waits for every load in
-          // flight (the ring would run empty once per trip).
-          __builtin_amdgcn_sched_barrier(0);
-          slot = plane_load<TD>(rD0, k + PD * NW * WAVE);                 // this slot's next chunk (past the plane: 0)
+          warp_chunk(pz, m, t);
           if (__builtin_amdgcn_inverse_ballot_w64(m)) atomicMax(&s_owner[t], k);     // last raster writer wins  :358
           keep_mask(m, chunk);
           k += NW * WAVE;
           j++;
           rowcol_advance(cd, rd, rc_step);
-          __builtin_amdgcn_sched_barrier(0);    // (and the next chunk's first instructions -- they wait for ITS slot -- stay behind)
         };
-        // PD chunks per trip (one per ring slot), written out by hand: the ballot / lane accesses are convergent
-        // operations, which the compiler will not duplicate for a run-time trip count (#pragma unroll is refused); the
-        // bounds are wave-uniform
-        static_assert(PD == 4, "the trips below are written out for four slots");
+        // two chunks per trip, written out by hand: the ballot / lane accesses are convergent operations, which the
+        // compiler will not duplicate for a run-time trip count (#pragma unroll is refused); the bounds are wave-uniform
         int chunk = wave;
-#ifdef PHOVO_AB_CLASSIC_PASS1       // A/B diagnostic build only: one chunk ahead, two chunks per trip, free scheduling (round 2)
-        {
-          double pz_n1 = pzr[0];
-          auto classic_body = [&](const int ch) {
-            const double pz = pz_n1;
-            pz_n1 = plane_load<TD>(rD0, k + NW * WAVE);
-            unsigned long long m;
-            int t;
-            warp_chunk(pz, m, t);
-            if (__builtin_amdgcn_inverse_ballot_w64(m)) atomicMax(&s_owner[t], k);
-            keep_mask(m, ch);
-            k += NW * WAVE;
-            j++;
-            rowcol_advance(cd, rd, rc_step);
-          };
-          for (; chunk + NW < A.n_chunks; chunk += 2 * NW) {
-            classic_body(chunk);
-            classic_body(chunk + NW);
-          }
-          if (chunk < A.n_chunks) classic_body(chunk);
-          chunk = A.n_chunks;
+        for (; chunk + NW < A.n_chunks; chunk += 2 * NW) {
+          chunk_body(chunk);
+          chunk_body(chunk + NW);
         }
-#endif
-        for (; chunk + 3 * NW < A.n_chunks; chunk += 4 * NW) {
-          chunk_body(chunk, pzr[0]);
-          chunk_body(chunk + NW, pzr[1]);
-          chunk_body(chunk + 2 * NW, pzr[2]);
-          chunk_body(chunk + 3 * NW, pzr[3]);
-        }
-        if (chunk < A.n_chunks) {
-          chunk_body(chunk, pzr[0]);
-          if (chunk + NW < A.n_chunks) {
-            chunk_body(chunk + NW, pzr[1]);
-            if (chunk + 2 * NW < A.n_chunks) chunk_body(chunk + 2 * NW, pzr[2]);
-          }
-        }
+        if (chunk < A.n_chunks) chunk_body(chunk);
       } else {
         // Owner map in HBM.  The memory counter of a wave retires in order, so a load issued behind a global atomic
         // waits for that atomic (about 2800 cycles with every CU issuing them): a loop of load - compute - atomic per
@@ -383,21 +298,8 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
         }
       }
     }
-    // The four planes of pass 2's first chunk do not depend on the owner map: they are requested in FRONT of the barrier
-    // (the owner and the gather it leads to follow behind it).
-    int o_n = -1;
-    double pz_n = 0.0, gx_n = 0.0, gy_n = 0.0, i1_n = 0.0, i0_n = 0.0;
-    auto fetch_planes = [&](int kk) {
-      pz_n = plane_load<TD>(rD0, kk);
-      gx_n = plane_load<TI>(rGX, kk);             // gradient at the SOURCE index  :346-347
-      gy_n = plane_load<TI>(rGY, kk);
-      i1_n = plane_load<TI>(rI1, kk);             // :309
-    };
-#ifdef PHOVO_AB_PREISSUE
-    if constexpr (OWNER_LDS) fetch_planes(k0);
-#endif
     PHOVO_STAMP(0)
-    wg_barrier<NW, GLOBAL_SYNC>();
+    __syncthreads();
     PHOVO_STAMP(1)
 
     // ---- pass 2: residual, Jacobian row, normal-equation accumulation ---------------------
@@ -416,11 +318,11 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
     auto pass2 = [&](auto huber_tag) {
       constexpr bool HUBER = decltype(huber_tag)::value;
       int k = k0, j = 0;
-      asm volatile("" : "+v"(k));
-      double cd, rd;
-      first_rowcol(cd, rd);
+      double cd = cd0, rd = rd0;
       // software prefetch, as in pass 1: owner + four planes of the NEXT chunk are requested (and the
       // gathered source intensity right behind them) before this chunk's arithmetic starts.
+      int o_n = -1;
+      double pz_n = 0.0, gx_n = 0.0, gy_n = 0.0, i1_n = 0.0, i0_n = 0.0;
       // Owner map in HBM: the entry is requested TWO chunks ahead (o_raw), so that the gather of the source
       // intensity one chunk ahead starts from an index that has already arrived instead of stalling on it; entries
       // of earlier iterations fail the tag comparison, so nothing is written back (a store per chunk would hold up
@@ -430,7 +332,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
         o_raw = (kk >= n_lds && kk < n) ? __hip_atomic_load(&g_owner[kk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
       };
       if (!OWNER_LDS) owner_request(k);
-      auto fetch_owner = [&](int kk) {
+      auto fetch = [&](int kk) {
         o_n = -1;
         if (OWNER_LDS) {
           if (kk < n) {
@@ -446,27 +348,14 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
           }
           owner_request(kk + NW * WAVE);
         }
-      };
-      auto gather_source = [&]() {
+        pz_n = plane_load<TD>(rD0, kk);
+        gx_n = plane_load<TI>(rGX, kk);             // gradient at the SOURCE index  :346-347
+        gy_n = plane_load<TI>(rGY, kk);
+        i1_n = plane_load<TI>(rI1, kk);             // :309
         if (SRC_LDS) { if (o_n >= 0) i0_n = s_i0[o_n]; }
         else i0_n = plane_load<TI>(rI0, o_n);       // :308 of the owning source pixel (o = -1: offset past the plane -> 0)
       };
-      auto fetch = [&](int kk) {
-        fetch_owner(kk);
-        fetch_planes(kk);
-        gather_source();
-      };
-#ifdef PHOVO_AB_PREISSUE
-      if constexpr (OWNER_LDS) {                    // the planes of the first chunk are on their way since before the barrier
-        fetch_owner(k);
-        gather_source();
-      } else {
-        fetch(k);
-      }
-#else
       fetch(k);
-#endif
-
       auto chunk_body = [&](const int chunk) {
         const int o = o_n;
         const double pz = pz_n, gxi = gx_n, gyi = gy_n, pixel2 = i1_n, pixel1 = i0_n;
@@ -539,16 +428,10 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
       }
     };
     if (huber_on) pass2(std::true_type{}); else pass2(std::false_type{});
-#ifndef PHOVO_AB_NO_VALID
-    acc[RED_VALID] = lane == 0 ? (double)n_rows : 0.0;
-#endif
-    // the depth ring of the NEXT iteration's pass 1 (the same chunks again; wasted if this was the pair's last iteration)
-#ifdef PHOVO_AB_PREISSUE
-    if constexpr (OWNER_LDS) {
-#pragma unroll
-      for (int i = 0; i < PD; i++) pzr[i] = plane_load<TD>(rD0, k0 + i * NW * WAVE);
-    }
-#endif
+    // The number of Jacobian rows filled rides through the reduction in a spare slot.  MASK_REG: lane j still holds chunk
+    // j's ballot -- its popcount is that chunk's rows, and the sum over lanes and waves is the pair's (three vector
+    // instructions per iteration instead of two scalar ones per chunk).
+    acc[RED_VALID] = MASK_REG ? (double)(__popc((unsigned)inb_lo) + __popc((unsigned)inb_hi)) : (lane == 0 ? (double)n_rows : 0.0);
 
     PHOVO_STAMP(2)
     // ---- wave-level transposed butterfly: 32 shuffles, lane l ends with value index idx(l) ----
@@ -563,7 +446,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
                       ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
       if ((lane & 1) == 0) s_red[wave * NRED + idx] = total;
     }
-    wg_barrier<NW, false>();
+    __syncthreads();
     PHOVO_STAMP(3)
 
     // ---- wave 0: cross-wave sum (fixed order), solve, update, terminate ------------------------
@@ -617,20 +500,11 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
         for (int i = 0; i < 6; i++) s_state[i] = st[i];
         s_ctl[CTL_DONE] = done ? 1 : (hand ? 2 : 0);
         if (!finite) s_ctl[CTL_FLAGS] |= (int)PHOVO_PAIR_NONFINITE;
+        if (last_valid < 6) s_ctl[CTL_FLAGS] |= (int)PHOVO_PAIR_RANK_DEFICIENT;
       }
       last_gnorm = gnorm;
     }
-    // Look-ahead, first iteration of a pair only: while wave 0 solves, the last wave -- idle at the barrier below
-    // otherwise -- draws the NEXT pair's ticket and fetches its descriptor (state, frame indices, starting iteration: one
-    // dword per lane) into the look-ahead block.  Two dependent trips to memory, in the shadow of the serial section; what
-    // the next pair's prologue finds is all in LDS.
-    if (wave == PFW && iteration == it0) {                                  // wave-uniform
-      int next_pair = 0;
-      if (lane == 0) next_pair = draw_end(A, draw_begin(A));
-      next_pair = __builtin_amdgcn_readfirstlane(next_pair);
-      lookahead_store(A, next_pair, lookahead_load(A, next_pair, lane), lane, s_next);
-    }
-    wg_barrier<NW, false>();
+    __syncthreads();
     PHOVO_STAMP(4)
     iteration++;
     const int done_word = s_ctl[CTL_DONE];
@@ -659,6 +533,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
 #endif
     }
     if (handed_over) handover_append(A, pair);
+    s_ctl[CTL_PAIR] = draw_pair_any(A);
   }
   }   // next pair
 }
@@ -885,7 +760,7 @@ constexpr size_t LDS_HALF = LDS_LIMIT / 2; // two workgroups per CU
 size_t lds_fixed_bytes(int threads)
 {
   const int nw = threads / WAVE;
-  return sizeof(double) * (32 + 8 + (size_t)nw * NRED) + sizeof(int) * (CTL_COUNT + NX_COUNT);   // (+ the look-ahead block)
+  return sizeof(double) * (32 + 8 + (size_t)nw * NRED) + sizeof(int) * CTL_COUNT;
 }
 
 static_assert((1 << OWNER_TAG_SHIFT) - 1 == OWNER_INDEX_MASK, "index mask and tag shift belong together");

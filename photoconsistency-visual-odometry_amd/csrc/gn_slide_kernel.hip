@@ -371,6 +371,7 @@ __global__ __launch_bounds__(T, T / 256) void gn_level_kernel_slide(const GNLeve
           for (int i = 0; i < 6; i++) s_state[i] = st[i];
           s_ctl[CTL_DONE] = done ? 1 : 0;
           if (!finite) s_ctl[CTL_FLAGS] |= (int)PHOVO_PAIR_NONFINITE;
+          if (n_valid < 6) s_ctl[CTL_FLAGS] |= (int)PHOVO_PAIR_RANK_DEFICIENT;
         }
         last_gnorm = gnorm;
         last_valid = n_valid;

@@ -135,6 +135,7 @@ __device__ __forceinline__ void wide_record(const GNLevelArgs &A, int pair, cons
     A.reports[pair].gradient_norm = w.gnorm;
     A.reports[pair].valid_pixels[A.level] = w.n_valid;
     if (!w.finite) A.reports[pair].flags |= PHOVO_PAIR_NONFINITE;
+    if (w.n_valid < 6) A.reports[pair].flags |= PHOVO_PAIR_RANK_DEFICIENT;
   }
 }
 

@@ -50,6 +50,13 @@ struct GNLevelArgs {
   int *handover_out;
   int iter_cap;
   unsigned takeover_flag;
+  // Levels that overlap (engine.cpp, enqueue): while the launches that finish the long pairs of the level before still run
+  // on a second stream, the first launch of this level takes every pair that is NOT waiting for them.
+  //   mark_out    non-null: a pair appended to handover_out also gets mark_out[pair] = 1 (zeroed per enqueue)
+  //   skip_marks  non-null (plain queue only): a drawn pair with skip_marks[pair] != 0 is not this launch's -- it is
+  //               drawn past (a later launch takes the marked pairs from the hand-over list they are on)
+  int *mark_out;
+  const int *skip_marks;
 };
 
 constexpr int QUEUES_PER_LEVEL = 8;      // one per XCD

@@ -16,6 +16,7 @@ MAX_LEVELS = 16
 ROLE_SOURCE, ROLE_TARGET, ROLE_BOTH = 1, 2, 3
 PAIR_NONFINITE = 1
 PAIR_WINDOW_FALLBACK = 2
+PAIR_RANK_DEFICIENT = 4
 # phovo_status
 OK, E_INVALID_ARGUMENT, E_CONFIG, E_SHAPE, E_HIP, E_NOT_READY, E_IO, E_UNSUPPORTED = range(8)
 

@@ -115,7 +115,7 @@ class LayeredScene:
             den = w @ sf["n"]
             with np.errstate(divide="ignore", invalid="ignore"):
                 s = (sf["d"] - sf["n"] @ o) / den
-            P = o + s[..., None] * w
+                P = o + s[..., None] * w
             uu, vv = P @ sf["u"], P @ sf["v"]
             ok = np.isfinite(s) & (s > 0.2) & (s < best)
             if sf["bounds"] is not None:

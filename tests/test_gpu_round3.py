@@ -270,9 +270,10 @@ def test_rank_deficient_normal_equations_are_flagged_or_agree(n_valid):
     """A source frame with only `n_valid` pixels of valid depth: J^T J has rank <= n_valid.  With fewer than six rows it is
     singular and NEITHER side can produce a meaningful step -- the reference inverts it with Eigen's pivoted LU
     (garbage or inf/NaN, silently), the device factorises it LDL^T without pivoting (a zero or rounding-noise pivot):
-    the two kinds of garbage need not agree, and this test pins what IS guaranteed: the device never reports such a
-    pair as a healthy one -- it ends non-finite and flagged, or (when rounding noise kept the pivots alive) with a state
-    that is as wild as the oracle's -- and the report's valid-pixel count says why.  From a well-posed count on (40 rows
+    the two kinds of garbage need not agree (and may both be finite: noise over noise), and this test pins what IS
+    guaranteed: the device never reports such a pair as a healthy one -- PHOVO_PAIR_RANK_DEFICIENT is set whenever the last
+    iteration of a level filled fewer than six rows, PHOVO_PAIR_NONFINITE when the state is not finite -- and the
+    report's valid-pixel count says why.  From a well-posed count on (40 rows
     spread over the image) both sides agree to the usual bar."""
     w, h = 160, 120
     p = synthetic.make_pair(350, w, h)
@@ -299,11 +300,114 @@ def test_rank_deficient_normal_equations_are_flagged_or_agree(n_valid):
         assert se3.state_distance(s[0], es) < 1e-7                 # 40 rows: conditioned well enough, not as well as 19 200
         assert reps[0].valid_pixels[0] == tr[-1]["valid_pixels"]
     elif n_valid < 6:
-        assert wild(es), "the oracle was expected to produce garbage from a singular J^T J"
-        assert wild(s[0]) or (reps[0].flags & native.PAIR_NONFINITE), (s[0], reps[0].flags)
+        # both sides divide rounding noise by rounding noise: the oracle's pivoted LU and the device's LDL^T give
+        # DIFFERENT finite or non-finite nonsense (observed: the oracle tens of metres, the device a few millimetres).
+        # What the device guarantees is the flag.
+        assert reps[0].flags & native.PAIR_RANK_DEFICIENT, (s[0], reps[0].flags)
+        assert reps[0].valid_pixels[0] < 6
         if not np.all(np.isfinite(s[0])):
             assert reps[0].flags & native.PAIR_NONFINITE
     else:                                                          # exactly six rows: square J, invertible but fragile
-        assert wild(s[0]) == wild(es) or (reps[0].flags & native.PAIR_NONFINITE)
+        assert reps[0].flags & native.PAIR_RANK_DEFICIENT == 0 or reps[0].valid_pixels[0] < 6
+        assert wild(s[0]) == wild(es) or (reps[0].flags & (native.PAIR_NONFINITE | native.PAIR_RANK_DEFICIENT))
     print(f"{n_valid} valid pixels: oracle {'garbage' if wild(es) else 'finite'}, device flags {reps[0].flags}, "
           f"device state {'garbage' if wild(s[0]) else 'finite'}, valid_pixels {reps[0].valid_pixels[0]}")
+
+
+# ---------------------------------------------------------------------------------------------
+# consecutive levels overlap on two streams: same results as on one
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("yml", ["config_4_level_optimization_analytic.yml", "config_5_level_optimization_analytic.yml"])
+def test_overlapping_levels_change_nothing_but_the_clock(yml, monkeypatch):
+    """With the shipped thresholds the follow-up launches of a capped level (the few long pairs) run on a second stream
+    while the next level's first launch takes every pair that is not waiting for them, and a second first launch takes
+    the rest afterwards (engine.cpp, enqueue).  Same kernels and geometries per pair either way: 1200 pairs (12 problems,
+    plane and layered, short and long ones, x 100) must come out BIT-identical with PHOVO_GN_OVERLAP=0 (everything on
+    one stream) -- states, iteration counts, valid pixels, gradient norms -- and equal to the oracle's."""
+    ncfg = native.read_config_file(os.path.join(CFG_DIR, yml))
+    nl = ncfg.num_levels
+    _, ocfg = _cfgs(nl, list(ncfg.max_num_iterations[:nl]), list(ncfg.min_gradient_norm[:nl]))
+    probs = [synthetic.make_pair(400 + i, 640, 480, holes=0.02, trans=(0.01, 0.03, 0.06)[i % 3], rot=(0.004, 0.012, 0.02)[i % 3])
+             for i in range(8)]
+    probs += [synthetic.make_pair(410 + i, 640, 480, scene="layered", trans=(0.03, 0.07)[i % 2], rot=0.01) for i in range(4)]
+    expect = [_oracle_with_counts(ocfg, p) for p in probs]
+    assert max(max(e[1]) for e in expect) > 4, "no pair exceeds the iteration cap: nothing is handed over"
+    src = [2 * (k % 12) for k in range(1200)]
+    tgt = [s + 1 for s in src]
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PHOVO_GN_OVERLAP", mode)
+        with odometry.AlignmentEngine() as eng:
+            eng.set_config(ncfg)
+            eng.set_batch_invariant(True)
+            eng.set_intrinsic_matrix(probs[0]["K"])
+            _upload_pairs(eng, probs, 640, 480)
+            a = eng.align_pairs(src, tgt, want_reports=True)
+            b = eng.align_pairs(src, tgt, want_reports=True)          # and again: lists, marks and queue heads start clean
+            total_ms, level_ms = eng.last_align_ms()
+        assert np.array_equal(a[0], b[0])
+        out[mode] = (a, total_ms, level_ms)
+    (s1, r1), t1, lv1 = out["1"]
+    (s0, r0), t0, lv0 = out["0"]
+    assert np.array_equal(s1, s0)
+    for x, y in zip(r1, r0):
+        assert list(x.iterations[:nl]) == list(y.iterations[:nl]) and x.flags == y.flags
+        assert list(x.valid_pixels[:nl]) == list(y.valid_pixels[:nl]) and x.gradient_norm == y.gradient_norm
+    for k in range(1200):
+        es, eits, ev, _ = expect[k % 12]
+        assert list(r1[k].iterations[:nl]) == eits, (k, list(r1[k].iterations[:nl]), eits)
+        assert se3.state_distance(s1[k], es) < POSE_TOL
+        assert list(r1[k].valid_pixels[:nl]) == ev
+    # on one stream the level spans add up to the whole; overlapped they exceed it
+    assert abs(sum(lv0) - t0) < 0.05 * t0 + 0.05
+    print(f"{yml}: one stream {t0:.3f} ms (levels {[round(v, 3) for v in lv0[:nl]]}), overlapped {t1:.3f} ms "
+          f"(level spans {[round(v, 3) for v in lv1[:nl]]})")
+
+
+# ---------------------------------------------------------------------------------------------
+# visualizeIterations, headless
+# ---------------------------------------------------------------------------------------------
+def test_visualize_iterations_writes_the_reference_difference_images(tmp_path, monkeypatch):
+    """`visualizeIterations: 1` (config_only_level_0_analytic.yml ships it): the reference shows |I1 - warped source| after
+    every iteration that does not end the level (...Analytic.h:515-517,359-362,551-557).  With PHOVO_VISUALIZE_DIR set the
+    class surface writes those images: one per non-final iteration, the first of a level equal -- byte for byte -- to what
+    the oracle's ComputeResidualsAndJacobians fills in at the level's starting state, and the poses the same as without
+    the images."""
+    p = synthetic.make_pair(420, 320, 240, scene="layered")
+    ncfg, ocfg = _cfgs(2, [3, 3], [0.0, 0.0])
+    es, eits, ev, pyr = _oracle_with_counts(ocfg, p)
+
+    def run(visualize):
+        cfg, _ = _cfgs(2, [3, 3], [0.0, 0.0])
+        cfg.visualize_iterations = visualize
+        with odometry.CPhotoconsistencyOdometryAnalytic() as po:
+            po.SetConfiguration(cfg)
+            po.SetIntrinsicMatrix(p["K"])
+            po.SetSourceFrame(p["gray0"], p["depth0"])
+            po.SetTargetFrame(p["gray1"], p["depth1"])
+            po.SetInitialStateVector(np.zeros(6))
+            po.Optimize()
+            return po.GetOptimalStateVector(), po.GetReport()
+
+    plain, rp = run(0)
+    ignored, _ = run(1)                                   # no directory: the key is parsed and ignored
+    assert np.array_equal(plain, ignored) and not list(tmp_path.iterdir())
+    monkeypatch.setenv("PHOVO_VISUALIZE_DIR", str(tmp_path))
+    shown, rs = run(1)
+    assert np.array_equal(shown, plain)                   # same kernels, one iteration per launch
+    assert list(rs.iterations[:2]) == list(rp.iterations[:2]) == eits == [3, 3]
+    assert list(rs.valid_pixels[:2]) == ev
+    assert se3.state_distance(shown, es) < POSE_TOL
+    names = sorted(f.name for f in tmp_path.iterdir())
+    assert names == [f"optimize_imgDiff_level{l}_iteration{i}.pgm" for l in (0, 1) for i in (1, 2)]
+    # level 1, iteration 1 was computed at the zero state
+    i0p, d0p, i1p, gxp, gyp = pyr
+    _, _, warped = oracle.compute_residuals_and_jacobians(i0p[1], d0p[1], i1p[1], gxp[1], gyp[1], 1, p["K"], np.zeros(6),
+                                                          want_warped=True)
+    want = np.rint(np.minimum(np.abs(i1p[1].reshape(-1) - warped) * 255.0, 255.0)).astype(np.uint8)
+    raw = (tmp_path / "optimize_imgDiff_level1_iteration1.pgm").read_bytes()
+    head = b"P5\n160 120\n255\n"
+    assert raw.startswith(head) and len(raw) == len(head) + 160 * 120
+    got = np.frombuffer(raw[len(head):], dtype=np.uint8)
+    assert np.array_equal(got, want)
+    assert 0 < int((got > 8).sum()) < got.size            # a real difference image: neither blank nor saturated

@@ -14,12 +14,18 @@ import phovo_amd  # noqa: E402,F401
 from phovo_amd import native, odometry, synthetic  # noqa: E402
 
 level = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-pairs, distinct = 2048, 32
+pairs = int(sys.argv[2]) if len(sys.argv) > 2 else 2048          # [pairs] [fixed iterations per pair: one uncapped launch]
+fixed = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+distinct = 32
 seq = synthetic.make_sequence(100, distinct + 1, 640, 480, holes=0.01)
 cfg = native.read_config_file(os.path.join(os.path.dirname(__file__), "..", "config_files",
                                            "config_4_level_optimization_analytic.yml"))
 if level == 3:                      # the stamps of the last level launched are the ones that stay in the report
     cfg.max_num_iterations[2] = 0
+if fixed:
+    for l in range(4):
+        cfg.min_gradient_norm[l] = 0.0
+    cfg.max_num_iterations[level] = fixed
 with odometry.AlignmentEngine() as eng:
     eng.set_config(cfg)
     eng.set_intrinsic_matrix(seq["K"])
@@ -42,6 +48,9 @@ b, e = (b - t0) / 100.0, (e - t0) / 100.0          # microseconds
 print(f"level {level}: launch {ms * 1e3:.0f} us by HIP events; first begin 0, last end {e.max():.0f} us; "
       f"workgroups {wg.max() + 1}; iterations mean {it.mean():.2f} max {it.max()}")
 dur = e - b
+cyc = np.array([[r.iterations[8 + j] for j in range(5)] for r in rp], dtype=np.float64).sum(axis=1)      # wave 0's cycles per iteration
+print(f"   wave 0 counts {cyc.mean():.0f} cycles per iteration over {np.mean(dur / np.maximum(it, 1)):.2f} us of wall clock: "
+      f"{cyc.mean() / np.mean(dur / np.maximum(it, 1)) / 1e3:.3f} GHz effective")
 for k in sorted(set(it)):
     m = it == k
     print(f"   {k:3d} iterations: {m.sum():5d} pairs, {dur[m].mean():7.1f} us per pair = {dur[m].mean() / k:6.1f} us per iteration; "
