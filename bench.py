@@ -85,6 +85,55 @@ def algorithmic_bytes(level_sizes, iterations):
     return sum(5.0 * 8.0 * n * it for n, it in zip(level_sizes, iterations))
 
 
+def capped_launch_work(it, level_sizes, max_iter, min_grad, plane_bytes, iter_cap=4, tail_stages=3):
+    """Pair-iterations and algorithmic bytes of EVERY launch of one enqueue with data-dependent termination, from the
+    iteration counts the pairs reported -- the schedule of csrc/engine.cpp (phovo_engine_enqueue_align), restated: a level
+    with a gradient threshold and max_num_iterations above the cap is a first launch capped at `iter_cap` iterations, then
+    (levels of >= 16384 pixels with max_num_iterations > 3 x cap) one capped at 3 x cap and a last one, or (smaller levels)
+    one last launch; with overlapping levels the next level's first launch leaves out the pairs the level before handed
+    over ("marked") and a second first launch takes exactly those.  Order = the order the host enqueues them in (what a
+    rocprofv3 trace lists by Dispatch_Id).  The reference has none of this: one Optimize() loop per pair (...Analytic.h:500-563)."""
+    iter_cap = int(os.environ.get("PHOVO_GN_ITER_CAP", iter_cap))
+    tail_stages = int(os.environ.get("PHOVO_GN_TAIL_STAGES", tail_stages))
+    overlap = os.environ.get("PHOVO_GN_OVERLAP", "1") != "0"
+    out = []
+    marked = np.zeros(len(it), dtype=bool)          # handed over by the level before, follow-ups possibly still in flight
+    pending = False                                 # the level before runs follow-ups beside this level (the host cannot know
+                                                    # whether any pair was handed over: the launches exist either way)
+    levels = [l for l in range(len(max_iter) - 1, -1, -1) if max_iter[l] > 0]
+    for li, l in enumerate(levels):
+        n_it = it[:, l].astype(np.int64)
+        capped = iter_cap > 0 and min_grad[l] > 0.0 and max_iter[l] > iter_cap
+
+        def add(name, pair_iterations, pairs):
+            out.append(dict(level=l, launch=name, pairs=int(pairs), pair_iterations=int(pair_iterations),
+                            algorithmic_bytes=float(plane_bytes * level_sizes[l] * pair_iterations)))
+        first_cap = iter_cap if capped else max_iter[l]
+        first = np.minimum(n_it, first_cap)
+        if pending:
+            add("first, pairs not waiting for the level before", first[~marked].sum(), (~marked).sum())
+        else:
+            add("first", first.sum(), len(n_it))
+        follow = []
+        if capped:
+            cap2 = 3 * iter_cap
+            if tail_stages >= 3 and max_iter[l] > cap2 and level_sizes[l] >= 16384:
+                mid = np.clip(n_it - iter_cap, 0, cap2 - iter_cap)
+                follow.append((f"follow-up, iterations {iter_cap + 1}..{cap2}", mid.sum(), (n_it > iter_cap).sum()))
+                follow.append((f"follow-up, iterations {cap2 + 1}..", np.maximum(n_it - cap2, 0).sum(), (n_it > cap2).sum()))
+            else:
+                follow.append((f"follow-up, iterations {iter_cap + 1}..", np.maximum(n_it - iter_cap, 0).sum(), (n_it > iter_cap).sum()))
+        # host order (engine.cpp): first launch, [second first launch for the marked pairs], then this level's follow-ups
+        if pending:
+            add("first, pairs handed over by the level before", first[marked].sum(), marked.sum())
+        for f in follow:
+            add(*f)
+        nxt_ok = li + 1 < len(levels)
+        pending = bool(capped and overlap and nxt_ok)
+        marked = (n_it > iter_cap) if pending else np.zeros(len(it), dtype=bool)
+    return out
+
+
 ZERO_COPY = {"ok": None}      # None = not probed yet; decided once by probe_zero_copy() outside the timed region
 
 
@@ -363,7 +412,9 @@ def main():
                         avg_enqueue_ms=float(lv2[native.MAX_LEVELS]) / k2,
                         note="per-level spans may overlap: the follow-up launches of a capped level run on a second stream "
                              "beside the next level's first launch; avg_enqueue_ms is first launch to last",
-                        iteration_histogram=hist)
+                        iteration_histogram=hist,
+                        launches=capped_launch_work(it2, level_sizes, max_iter,
+                                                    [float(cfg_ref.min_gradient_norm[l]) for l in range(nl)], plane_bytes))
 
     # ---- PCIe-inclusive figure (never `value`): raw frames in host memory -> poses --------------------------
     # batched u16-depth upload + device pyramids + Optimize() with the shipped thresholds, one sequence of
@@ -519,6 +570,8 @@ def main():
             "cpu_baseline": cpu,
             "cpu_baseline_all_cores": cpu_all,
             "reference_termination": ref_term,
+            # --thresholds shipped (diagnostic): every launch of the timed enqueue with its share of the work, host order
+            "launches": capped_launch_work(iters, level_sizes, max_iter, min_grad_timed, plane_bytes) if shipped else None,
             "end_to_end_pcie_inclusive": e2e,
             "single_pair": single,
         }

@@ -36,6 +36,25 @@ __device__ __forceinline__ double uniform_f64(double v)
   return __hiloint2double(hi, lo);
 }
 
+// A/B switch, OFF in the shipped build (-DPHOVO_AB_SERIAL_PRIO turns it on; tools/ only).  The serial sections of a
+// workgroup -- a pair's prologue (state, sincos, pose constants), wave 0's solve / update / pose constants of every
+// iteration, the write-back and the draw of the next pair -- are a few hundred DEPENDENT fp64 instructions of ONE wave
+// while the other waves of its workgroup stand at a barrier; with four waves per SIMD that wave gets about every fourth
+// issue slot (the pose constants take 1.2 us for a pair alone on its CU and 5.4 us on a full chip: 5.4 of the 9 us
+// between two pairs of a workgroup, tools/queue_timeline.py).  Raising its priority (s_setprio 3) was measured in round 3
+// and is NOT kept: shipped thresholds 1.649 -> 1.617 M alignments/s (-2 %), every plane streamed once +1 %, fixed
+// iterations -0.2 %: the chip is bound by vector issue, so the slots the serial wave wins are slots the streaming waves
+// of the other workgroups lose -- the gap between a workgroup's pairs is not idle time of the CU.  (s_setprio is a scalar
+// instruction and ignores EXEC: wave-uniform control only.)
+__device__ __forceinline__ void serial_priority(bool on)
+{
+#ifdef PHOVO_AB_SERIAL_PRIO
+  if (on) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+#else
+  (void)on;
+#endif
+}
+
 // Pose constants from the state: Rt (:219-241) and temp1..temp24 (:243-266), written with the
 // reference's association.  temp7 = -temp6, temp9 = -temp8, temp21 = -temp5, temp22 = temp2,
 // temp23 = temp1 hold exactly in IEEE arithmetic and are not stored; Rt(0,0) = temp15,
@@ -331,6 +350,7 @@ __device__ __forceinline__ void reduce_solve_update(double (&acc)[NRED], int lan
   }
   __syncthreads();
   if (wave == 0) {
+    serial_priority(true);
     double v = 0.0;
     {
       const int j = lane & (NRED - 1);
@@ -371,6 +391,7 @@ __device__ __forceinline__ void reduce_solve_update(double (&acc)[NRED], int lan
       if (last_valid < 6) s_ctl[CTL_FLAGS] |= (int)PHOVO_PAIR_RANK_DEFICIENT;
     }
     last_gnorm = gnorm;
+    serial_priority(false);
   }
   __syncthreads();
 }

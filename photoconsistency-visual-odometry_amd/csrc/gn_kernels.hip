@@ -79,6 +79,10 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
   // The owner map in LDS is wiped ONCE per workgroup: pass 2 resets every slot it reads, and it reads all of them.
   for (int k = tid; k < (OWNER_LDS ? n : n_lds); k += T) s_owner[k] = -1;
   if (tid == 0) s_ctl[CTL_PAIR] = draw_pair_any(A);
+#ifdef PHOVO_STAMPS
+  // diagnostic build only: where the time between two pairs of a workgroup goes (100 MHz wall clock, thread 0's view)
+  unsigned gp_end = 0, gp_draw = 0, gp_top = 0, gp_state = 0, gp_cst = 0;
+#endif
   for (;;) {
   // The ticket thread 0 has just stored must have LEFT its LDS queue before any wave is released: the compiler omits
   // the wait in front of this one barrier (it relies on LDS operations being ordered across waves), and on the GPU
@@ -88,6 +92,9 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
   __syncthreads();
   const int pair = __builtin_amdgcn_readfirstlane(s_ctl[CTL_PAIR]);
   if (pair >= A.n_pairs) break;           // uniform: every wave of the workgroup leaves together
+#ifdef PHOVO_STAMPS
+  gp_top = (unsigned)wall_clock64();
+#endif
 
   const unsigned char *src_frame = A.planes + (size_t)A.src[pair] * A.frame_bytes;
   const unsigned char *tgt_frame = A.planes + (size_t)A.tgt[pair] * A.frame_bytes;
@@ -110,9 +117,14 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
     for (int k = tid; k < n; k += T) s_i0[k] = plane_load<TI>(rI0, k);
   }
   if (wave == 0) {
+    serial_priority(true);          // (gn_device.hpp: the other waves of the workgroup wait for this one)
     double st[6];
 #pragma unroll
     for (int j = 0; j < 6; j++) st[j] = A.states[(size_t)pair * 6 + j];
+#ifdef PHOVO_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(st[0]), "+v"(st[1]), "+v"(st[2]), "+v"(st[3]), "+v"(st[4]), "+v"(st[5]) :: "memory");
+    gp_state = (unsigned)wall_clock64();
+#endif
     write_pose_constants(st[0], st[1], st[2], st[3], st[4], st[5], s_cst, lane);
     if (lane == 0) {
 #pragma unroll
@@ -120,6 +132,11 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
       s_ctl[CTL_DONE] = 0;
       s_ctl[CTL_FLAGS] = 0;
     }
+#ifdef PHOVO_STAMPS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    gp_cst = (unsigned)wall_clock64();
+#endif
+    serial_priority(false);
   }
   __syncthreads();
 
@@ -451,6 +468,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
 
     // ---- wave 0: cross-wave sum (fixed order), solve, update, terminate ------------------------
     if (wave == 0) {
+      serial_priority(true);
       PHOVO_SUBSTAMP_BEGIN
       // lane l sums value (l & 31) over half of the waves, the halves meet in one shuffle
       double v = 0.0;
@@ -503,6 +521,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
         if (last_valid < 6) s_ctl[CTL_FLAGS] |= (int)PHOVO_PAIR_RANK_DEFICIENT;
       }
       last_gnorm = gnorm;
+      serial_priority(false);
     }
     __syncthreads();
     PHOVO_STAMP(4)
@@ -512,6 +531,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
   }
 
   // ---- epilogue: state and report back to HBM -------------------------------------------------
+  if (wave == 0) serial_priority(true);       // (dropped again at the head of the next pair's prologue ... or by the exit)
   if (tid == 0) {
 #pragma unroll
     for (int j = 0; j < 6; j++) A.states[(size_t)pair * 6 + j] = s_state[j];
@@ -530,10 +550,22 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
       A.reports[pair].iterations[13] = (int)(unsigned)st_begin;
       A.reports[pair].iterations[14] = (int)(unsigned)wall_clock64();
       A.reports[pair].iterations[15] = (int)blockIdx.x;
+      // the gap in front of THIS pair: end of the pair before (0: none), its draw done, loop-top barrier passed, state
+      // loaded, pose constants written; iterations[13] is the end of the prologue barrier
+      A.reports[pair].valid_pixels[8] = (int)gp_end;
+      A.reports[pair].valid_pixels[9] = (int)gp_draw;
+      A.reports[pair].valid_pixels[10] = (int)gp_top;
+      A.reports[pair].valid_pixels[11] = (int)gp_state;
+      A.reports[pair].valid_pixels[12] = (int)gp_cst;
+      gp_end = (unsigned)wall_clock64();
 #endif
     }
     if (handed_over) handover_append(A, pair);
     s_ctl[CTL_PAIR] = draw_pair_any(A);
+#ifdef PHOVO_STAMPS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    gp_draw = (unsigned)wall_clock64();
+#endif
   }
   }   // next pair
 }

@@ -66,3 +66,16 @@ for w in range(wg.max() + 1):
     o = m[np.argsort(b[m])]
     gap += list(b[o][1:] - e[o][:-1])
 print(f"   between a workgroup's pairs (write-back, draw, prologue): mean {np.mean(gap):.1f} us, max {np.max(gap):.1f} us, n {len(gap)}")
+# where that time goes (thread 0's stamps, valid_pixels[8..12] of the stamp build): end of the pair before -> its ticket
+# drawn (write-back + atomic) -> loop-top barrier passed -> state loaded -> pose constants written -> prologue barrier
+vp = np.array([[r.valid_pixels[8 + j] for j in range(5)] for r in rp], dtype=np.int64) & 0xFFFFFFFF
+b_raw = np.array([r.iterations[13] for r in rp], dtype=np.int64) & 0xFFFFFFFF
+m = vp[:, 0] != 0                                  # pairs that had a predecessor on their workgroup
+if m.any():
+    pts = np.concatenate([vp[m], b_raw[m, None]], axis=1).astype(np.float64) / 100.0
+    d = np.diff(pts, axis=1)
+    keep = (pts[:, -1] - pts[:, 0]) < 200.0        # (a workgroup that waited for the next launch is not a gap)
+    names = ["write-back + draw", "to loop-top barrier", "frame indices + state load", "sincos + pose constants", "prologue barrier"]
+    print(f"   gap breakdown over {int(keep.sum())} pairs (us): " +
+          ", ".join(f"{nm} {d[keep, j].mean():.2f}" for j, nm in enumerate(names)) +
+          f"; total {(pts[keep, -1] - pts[keep, 0]).mean():.2f}")
