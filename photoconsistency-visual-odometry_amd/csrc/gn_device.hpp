@@ -68,7 +68,42 @@ __device__ __forceinline__ void write_pose_constants(double x, double y, double 
   // results are then broadcast (the whole wave executes this with a wave-uniform state).
   const double ang = (lane == 1) ? pitch : ((lane == 2) ? roll : yaw);
   double sn, cs;
-  sincos(ang, &sn, &cs);
+  // Euler angles of a frame-to-frame motion are small: up to pi/4 the two minimax polynomials of fdlibm's __kernel_sin /
+  // __kernel_cos (errors below one ulp, as the library's) need no argument reduction; anything larger takes the device
+  // library's sincos (wave-uniform branch: lanes 3.. carry yaw).  The library call alone cost 4.7 k cycles per iteration
+  // for a reason that has nothing to do with arithmetic: its polynomial coefficients are VGPR immediates that the
+  // compiler hoists to the top of the kernel, cannot keep under the 128-register cap and SPILLS -- nine dependent
+  // scratch reloads, each a full trip to memory behind an s_waitcnt vmcnt(0), in the middle of wave 0's serial section
+  // (and nine more in every pair's prologue).  Here the coefficients are scalar operands (opaque to the hoisting).
+#ifdef PHOVO_AB_LIB_SINCOS        // A/B diagnostic build only (tools/): always the library
+  const bool small_angles = false;
+#else
+  const bool small_angles = __builtin_amdgcn_ballot_w64(!(fabs(ang) <= 0.78539816339744828)) == 0;
+#endif
+  if (small_angles) {
+    auto k = [](double v) { asm volatile("" : "+s"(v)); return v; };       // a coefficient as an SGPR pair
+    const double z = ang * ang;
+    double ps = fma(z, k(1.58969099521155010221e-10), k(-2.50507602534068634195e-08));
+    double pc = fma(z, k(-1.13596475577881948265e-11), k(2.08757232129817482790e-09));
+    ps = fma(z, ps, k(2.75573137070700676789e-06));
+    pc = fma(z, pc, k(-2.75573143513906633035e-07));
+    ps = fma(z, ps, k(-1.98412698298579493134e-04));
+    pc = fma(z, pc, k(2.48015872894767294178e-05));
+    ps = fma(z, ps, k(8.33333333332248946124e-03));
+    pc = fma(z, pc, k(-1.38888888888741095749e-03));
+    ps = fma(z, ps, k(-1.66666666666666324348e-01));
+    pc = fma(z, pc, k(4.16666666666666019037e-02));
+    sn = fma(ang * z, ps, ang);                         // x + x^3 (S1 + z (S2 + ...)): 0.63 ulp at worst
+    // cos = 1 - z/2 + z^2 (C1 + z (C2 + ...)), summed as fdlibm does: from 0.3 upwards a quarter of |x| (truncated to
+    // its high word, so that 1 - qx and z/2 - qx are exact) is taken out of both big terms first: 0.77 ulp at worst
+    // (1.2 ulp summed naively)
+    const double ax = fabs(ang);
+    const double q4 = __hiloint2double(__double2hiint(ax) - 0x00200000, 0);
+    const double qx = ax < 0.3 ? 0.0 : (ax > 0.78125 ? 0.28125 : q4);
+    cs = (1.0 - qx) - fma(-z, z * pc, 0.5 * z - qx);
+  } else {
+    sincos(ang, &sn, &cs);
+  }
   const double sy = __shfl(sn, 0, WAVE), cy = __shfl(cs, 0, WAVE);
   const double sp = __shfl(sn, 1, WAVE), cp = __shfl(cs, 1, WAVE);
   const double sr = __shfl(sn, 2, WAVE), cr = __shfl(cs, 2, WAVE);

@@ -459,9 +459,13 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
     reduce_stage<2, 4>(acc, lane, 2);
     {
       const double total = acc[0] + __shfl_xor(acc[0], 1, WAVE);
-      const int idx = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 +
-                      ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
-      if ((lane & 1) == 0) s_red[wave * NRED + idx] = total;
+      // (the lane is made opaque here: the row address below is loop-invariant, and hoisted out of the iteration loop it
+      // does not survive pass 2's register pressure -- it came back as a scratch reload behind an s_waitcnt vmcnt(0),
+      // in every wave, right in front of the barrier wave 0's solve waits at; five integer instructions instead)
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      const int idx = ((ln >> 5) & 1) * 16 + ((ln >> 4) & 1) * 8 + ((ln >> 3) & 1) * 4 + ((ln >> 2) & 1) * 2 + ((ln >> 1) & 1);
+      if ((ln & 1) == 0) s_red[wave * NRED + idx] = total;
     }
     __syncthreads();
     PHOVO_STAMP(3)
