@@ -270,14 +270,27 @@ constexpr int OWNER_TAG_SHIFT = 21;
 constexpr int OWNER_INDEX_MASK = (1 << OWNER_TAG_SHIFT) - 1;      // levels of up to 2 097 151 pixels
 constexpr int OWNER_TAG_PERIOD = 1023;
 
+// Entries of an owner map kept in LDS for a level of n pixels and a workgroup of `threads` threads: whole 64-pixel chunks
+// plus one round of the workgroup's chunks (see gn_level_kernel: pass 2 reads a chunk ahead, unguarded).  Even.
+__host__ __device__ __forceinline__ constexpr int owner_lds_entries(int n, int threads)
+{
+  return ((n + 63) & ~63) + threads;
+}
+
 // C round() -- half away from zero (...Analytic.h:297-298) -- for arguments > -0.5, which is all the bounds test lets
-// through: trunc, exact fraction, +1 when the fraction reaches one half.  Five instructions; the library round() also
-// carries the sign through (seven).  (-0.5, 0) gives +0 where round() gives -0: both are pixel 0.
+// through, in TWO instructions: floor(v + p) with p = 0.49999999999999994, the largest double below one half.  Exact, not
+// approximately right (tests/test_oracle_properties.py checks every neighbour of every tie against exact arithmetic):
+//   * a tie v = n + 0.5 gives n + 1 - 2^-54, which rounds to n + 1 (the next double below n + 1 is at least 2^-53 away for
+//     n >= 1; for n = 0 the sum is halfway between 1 - 2^-53 and 1 and ties-to-even picks 1): round() says n + 1;
+//   * the largest double below a tie, n + 0.5 - ulp, gives a sum that rounds to at most n + 1 - ulp: floor is n -- also
+//     for 0.49999999999999994 itself, where the obvious floor(v + 0.5) goes wrong (the sum rounds up to 1.0);
+//   * anything else is further than an ulp from a tie and the sum's rounding cannot carry it across an integer;
+//   * (-0.5, 0) gives a sum in [0, 0.5): pixel 0, as round()'s -0.
+// The trunc / fraction / compare / select / add form this replaces was five instructions per coordinate: 6 of the 50 of a
+// pass-1 chunk (256 k -> 261 k alignments/s; the 5-level configuration, whose 40x30 level is vector-bound, +5 %).
 __device__ __forceinline__ double round_half_up_from(double v)
 {
-  const double t = trunc(v);
-  const double f = v - t;                                              // exact
-  return t + __hiloint2double(f >= 0.5 ? 0x3ff00000 : 0, 0);          // + 1.0 or + 0.0: one select on the high word
+  return floor(v + __hiloint2double(0x3fdfffff, (int)0xffffffff));
 }
 
 // Next pair of the work queue for the calling workgroup (one thread calls this), or n_pairs when everything is taken.
@@ -362,6 +375,26 @@ __device__ __forceinline__ void rowcol_advance(double &cd, double &rd, const Row
   const bool wrap = cd >= s.w;
   cd -= __hiloint2double(wrap ? s.hi_w : 0, 0);
   rd += __hiloint2double(wrap ? s.hi_step_r1 : s.hi_step_r, 0);
+}
+
+// (row, column) of pixel k from k itself, all in fp64: row = trunc((k + 0.5) / W), column = k - row * W.  Exact: k < 2^21
+// and W are integers, (k + 0.5) / W lies at least 0.5 / W >= 2.4e-7 away from every integer while the fma below is off by
+// less than (k / W) * 2^-52 < 1e-12, so the truncation cannot land on the wrong side; the column is an exact integer fma.
+struct RowColFromIndex {
+  double inv_w, half_inv_w, w;
+};
+__device__ __forceinline__ RowColFromIndex make_rowcol_from_index(int W)
+{
+  RowColFromIndex m;
+  m.w = (double)W;
+  m.inv_w = uniform_f64(1.0 / m.w);
+  m.half_inv_w = 0.5 * m.inv_w;
+  return m;
+}
+__device__ __forceinline__ void rowcol_from_index(double kd, const RowColFromIndex &m, double &cd, double &rd)
+{
+  rd = trunc(fma(kd, m.inv_w, m.half_inv_w));
+  cd = fma(-rd, m.w, kd);
 }
 
 // Wave butterfly + cross-wave sum + solve + update + termination, as in gn_level_kernel's tail, for kernels

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
   unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(s_ctl + CTL_COUNT);  // [n_chunks] (!MASK_REG)
   unsigned char *p = reinterpret_cast<unsigned char *>(s_mask + (MASK_REG ? 0 : A.n_chunks));
   int *s_owner = reinterpret_cast<int *>(p);                           // [n] (OWNER_LDS) or [n_lds] (owner map in HBM)
-  if (OWNER_LDS) p += sizeof(int) * ((A.n + 1) & ~1);
+  if (OWNER_LDS) p += sizeof(int) * (size_t)owner_lds_entries(A.n, T);
   const int n_lds = OWNER_LDS ? 0 : A.n_lds;      // owner map in HBM: targets below n_lds are resolved in LDS all the same
   double *s_i0 = reinterpret_cast<double *>(p);                        // [n]      (SRC_LDS)
 
@@ -77,7 +77,9 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
   // barrier with thread 0 parked: a hang).
   // (draw_pair_any: with handover_in the pairs come from the list an earlier launch of this level left behind)
   // The owner map in LDS is wiped ONCE per workgroup: pass 2 resets every slot it reads, and it reads all of them.
-  for (int k = tid; k < (OWNER_LDS ? n : n_lds); k += T) s_owner[k] = -1;
+  // It is padded to whole chunks plus one round of the workgroup (owner_lds_entries): pass 2 fetches the owner a chunk
+  // ahead without asking whether that chunk still exists -- the padding reads -1, "nobody", and pass 1 never writes there.
+  for (int k = tid; k < (OWNER_LDS ? owner_lds_entries(n, T) : n_lds); k += T) s_owner[k] = -1;
   if (tid == 0) s_ctl[CTL_PAIR] = draw_pair_any(A);
 #ifdef PHOVO_STAMPS
   // diagnostic build only: where the time between two pairs of a workgroup goes (100 MHz wall clock, thread 0's view)
@@ -153,10 +155,23 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
   // A wave walks the image in chunks of 64 consecutive pixels, NW chunks apart; (row, column) of a
   // lane's pixel is carried along instead of divided out per pixel.
   const int k0 = wave * WAVE + lane;
+#ifdef PHOVO_AB_ROWCOL_CARRY       // A/B diagnostic build only (tools/): (row, column) carried with compare-and-wrap, round 2
   const int r0 = k0 / W, c0 = k0 - r0 * W;
   const int step_r = (NW * WAVE) / W, step_c = (NW * WAVE) - step_r * W;
   const RowColStep rc_step = make_rowcol_step(step_r, step_c, W);
   const double cd0 = (double)c0, rd0 = (double)r0;
+#define PHOVO_ROWCOL_BEGIN double cd = cd0, rd = rd0;
+#define PHOVO_ROWCOL_HERE
+#define PHOVO_ROWCOL_NEXT rowcol_advance(cd, rd, rc_step);
+#else
+  // (row, column) of a lane's pixel from its linear index, carried as a double: four instructions per chunk (add, fma,
+  // trunc, fma) instead of the six of a carried pair with compare-and-wrap, and two registers less across the loops
+  const RowColFromIndex rc_map = make_rowcol_from_index(W);
+  const double kd0 = (double)k0, kd_step = (double)(NW * WAVE);
+#define PHOVO_ROWCOL_BEGIN double kd = kd0, cd, rd;
+#define PHOVO_ROWCOL_HERE rowcol_from_index(kd, rc_map, cd, rd);
+#define PHOVO_ROWCOL_NEXT kd += kd_step;
+#endif
 
   int iteration = 0;                // continuing a pair an earlier launch handed over: its completed iterations count
   if (A.handover_in) iteration = __builtin_amdgcn_readfirstlane(A.reports[pair].iterations[A.level]);
@@ -205,7 +220,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
     int n_rows = 0;                 // Jacobian rows this wave fills in this iteration (!MASK_REG: popcount of the ballots as they come)
     {
       int k = k0, j = 0;
-      double cd = cd0, rd = rd0;
+      PHOVO_ROWCOL_BEGIN
       // software prefetch: the depth of the NEXT chunk is requested before this chunk is processed, so
       // every wave keeps a load in flight while it computes (the passes are bound by bytes in flight per CU)
       double pz_next = plane_load<TD>(rD0, k);
@@ -214,11 +229,12 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
       double cxv = cx, cyv = cyy, czv = cz;
       asm volatile("" : "+v"(cxv), "+v"(cyv), "+v"(czv));
       // warp of one 64-pixel chunk: ballot of "valid and landed in bounds" and the target index of every lane
-      auto warp_chunk = [&](const double pz, unsigned long long &m_out, int &t_out) {
+      auto warp_chunk = [&](const double pz, const int chunk, unsigned long long &m_out, int &t_out) {
         // No branch around the arithmetic: a lane that fails the depth gate computes on whatever it loaded and is
         // dropped by `valid` below (a whole wave of invalid pixels is rare), and the ballot of a flat condition is
         // the AND of the compare masks -- scalar work only.
         // depth gate: k < n, min_d < pz < max_d  (:280), folded into the ballot below
+        PHOVO_ROWCOL_HERE
         const double px = (cd - ox) * pz * ifx;                           // :282
         const double py = (rd - oy) * pz * ify;                           // :283
         const double X = fma(r02, pz, fma(r01, py, fma(t15, px, cxv)));   // Rt*point3D  :291
@@ -232,8 +248,11 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
         const double rr = round_half_up_from(tr), rc = round_half_up_from(tc);
         // One ballot per comparison, ANDed on the scalar unit: the ballot of an AND of comparisons would be
         // rebuilt lane by lane (v_cndmask + v_cmp) by this compiler.
+        // (k < n is a property of the chunk, not of the lane: the lanes of the image's last, partial chunk -- scalar unit)
+        const int lanes_left = n - chunk * WAVE;
+        const unsigned long long in_image = lanes_left >= WAVE ? ~0ull : ((1ull << lanes_left) - 1ull);
         const unsigned long long m =
-            __builtin_amdgcn_ballot_w64(k < n) & __builtin_amdgcn_ballot_w64(min_d < pz) &
+            in_image & __builtin_amdgcn_ballot_w64(min_d < pz) &
             __builtin_amdgcn_ballot_w64(pz < max_d) & __builtin_amdgcn_ballot_w64(tr > -0.5) &
             __builtin_amdgcn_ballot_w64(rr < dH) & __builtin_amdgcn_ballot_w64(tc > -0.5) &
             __builtin_amdgcn_ballot_w64(rc < dW);
@@ -255,12 +274,12 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
           pz_next = plane_load<TD>(rD0, k + NW * WAVE);                   // past the plane: 0
           unsigned long long m;
           int t;
-          warp_chunk(pz, m, t);
+          warp_chunk(pz, chunk, m, t);
           if (__builtin_amdgcn_inverse_ballot_w64(m)) atomicMax(&s_owner[t], k);     // last raster writer wins  :358
           keep_mask(m, chunk);
           k += NW * WAVE;
           j++;
-          rowcol_advance(cd, rd, rc_step);
+          PHOVO_ROWCOL_NEXT
         };
         // two chunks per trip, written out by hand: the ballot / lane accesses are convergent operations, which the
         // compiler will not duplicate for a run-time trip count (#pragma unroll is refused); the bounds are wave-uniform
@@ -291,14 +310,14 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
 #pragma unroll
           for (int g = 0; g < G; g++) {
             if (chunk < A.n_chunks) {                                     // wave-uniform
-              warp_chunk(pzg[g], pend_m[g], pend_t[g]);
+              warp_chunk(pzg[g], chunk, pend_m[g], pend_t[g]);
               pend_v[g] = owner_tag | k;
               keep_mask(pend_m[g], chunk);
               count = g + 1;
               chunk += NW;
               k += NW * WAVE;
               j++;
-              rowcol_advance(cd, rd, rc_step);
+              PHOVO_ROWCOL_NEXT
             }
           }
 #pragma unroll
@@ -335,7 +354,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
     auto pass2 = [&](auto huber_tag) {
       constexpr bool HUBER = decltype(huber_tag)::value;
       int k = k0, j = 0;
-      double cd = cd0, rd = rd0;
+      PHOVO_ROWCOL_BEGIN
       // software prefetch, as in pass 1: owner + four planes of the NEXT chunk are requested (and the
       // gathered source intensity right behind them) before this chunk's arithmetic starts.
       int o_n = -1;
@@ -352,10 +371,8 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
       auto fetch = [&](int kk) {
         o_n = -1;
         if (OWNER_LDS) {
-          if (kk < n) {
-            o_n = s_owner[kk];
-            s_owner[kk] = -1;                       // ready for the next iteration
-          }
+          o_n = s_owner[kk];                        // (past the image: the padding, -1)
+          s_owner[kk] = -1;                         // ready for the next iteration
         } else {
           if (kk < n_lds) {                         // n_lds is a multiple of 64: the whole chunk is on one side
             o_n = s_owner[kk];
@@ -383,6 +400,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
                      : s_mask[chunk];
         if (__builtin_amdgcn_inverse_ballot_w64(mbits)) {                 // the ballot becomes the exec mask
           const double res = (o >= 0) ? (pixel2 - pixel1) : 0.0;          // :358
+          PHOVO_ROWCOL_HERE
           const double px = (cd - ox) * pz * ifx;
           const double py = (rd - oy) * pz * ify;
 
@@ -436,7 +454,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
         }
         k += NW * WAVE;
         j++;
-        rowcol_advance(cd, rd, rc_step);
+        PHOVO_ROWCOL_NEXT
       };
       // two chunks per trip by hand, as in pass 1
       for (int chunk = wave; chunk < A.n_chunks; chunk += 2 * NW) {
@@ -824,7 +842,7 @@ bool gn_plan_level(int n, GNLaunchPlan *plan, int prefer_latency)
 {
   plan->owner_lds_entries = 0;
   const size_t n_chunks = (size_t)(n + WAVE - 1) / WAVE;
-  const size_t owner = sizeof(int) * (size_t)((n + 1) & ~1);
+  auto owner_bytes = [n](int threads) { return sizeof(int) * (size_t)owner_lds_entries(n, threads); };
   const size_t src = sizeof(double) * (size_t)n;
   // Levels of <= 2048 pixels in a throughput launch: ONE WAVE per pair, 16 workgroups per CU.  An iteration of such a level
   // is short (40x30: 19 chunks) and a third of a 256-thread workgroup's time per iteration is wave 0's serial section
@@ -833,12 +851,12 @@ bool gn_plan_level(int n, GNLaunchPlan *plan, int prefer_latency)
   static const bool no_solo = std::getenv("PHOVO_GN_NO_SOLO") != nullptr;
   if (n <= 2048 && !prefer_latency && !no_solo && n_chunks <= 64) {
     plan->variant = V_SOLO; plan->threads = 64; plan->wgs_per_cu = 16; plan->owner_in_lds = true; plan->source_in_lds = false;
-    plan->lds_bytes = (int)(lds_fixed_bytes(64) + owner);
+    plan->lds_bytes = (int)(lds_fixed_bytes(64) + owner_bytes(64));
     return true;
   }
   if (n <= 2048) {
     plan->variant = V_TINY; plan->threads = 256; plan->wgs_per_cu = 4; plan->owner_in_lds = true; plan->source_in_lds = true;
-    plan->lds_bytes = (int)(lds_fixed_bytes(256) + owner + src);
+    plan->lds_bytes = (int)(lds_fixed_bytes(256) + owner_bytes(256) + src);
     return true;
   }
   const size_t f256 = lds_fixed_bytes(256);
@@ -849,29 +867,29 @@ bool gn_plan_level(int n, GNLaunchPlan *plan, int prefer_latency)
   // (one pair alone on a CU: 12.4 us per 80x60 iteration with 256 threads, 10.1 us with 512 -- prefer_latency)
   // experiment (tools/ only): two 512-thread workgroups per CU with the source intensity plane staged in LDS
   static const bool duo = std::getenv("PHOVO_GN_DUO") != nullptr;
-  if (duo && !prefer_latency && n_chunks <= 64 * 8 && lds_fixed_bytes(512) + owner + src <= LDS_HALF) {
+  if (duo && !prefer_latency && n_chunks <= 64 * 8 && lds_fixed_bytes(512) + owner_bytes(512) + src <= LDS_HALF) {
     plan->variant = V_DUO; plan->threads = 512; plan->wgs_per_cu = 2; plan->owner_in_lds = true; plan->source_in_lds = true;
-    plan->lds_bytes = (int)(lds_fixed_bytes(512) + owner + src);
+    plan->lds_bytes = (int)(lds_fixed_bytes(512) + owner_bytes(512) + src);
     return true;
   }
-  if (!no_quad && !prefer_latency && n_chunks <= 64 * 4 && f256 + owner <= LDS_LIMIT / 4) {
+  if (!no_quad && !prefer_latency && n_chunks <= 64 * 4 && f256 + owner_bytes(256) <= LDS_LIMIT / 4) {
     plan->variant = V_QUAD; plan->threads = 256; plan->wgs_per_cu = 4; plan->owner_in_lds = true; plan->source_in_lds = false;
-    plan->lds_bytes = (int)(f256 + owner);
+    plan->lds_bytes = (int)(f256 + owner_bytes(256));
     return true;
   }
   const size_t f512 = lds_fixed_bytes(512), f1024 = lds_fixed_bytes(1024);
   const bool reg512 = n_chunks <= 64 * 8, reg1024 = n_chunks <= 64 * 16;
   static const bool force_wide = std::getenv("PHOVO_GN_FORCE_WIDE") != nullptr;     // tuning aid
   // prefer_latency == 2: the widest workgroup that keeps the owner map in LDS (a pair alone on its CU: 16 waves instead of 8)
-  const bool widest = prefer_latency >= 2 && reg1024 && f1024 + owner <= LDS_LIMIT && n_chunks >= 64;
-  if (!force_wide && !widest && reg512 && f512 + owner <= LDS_HALF) {
+  const bool widest = prefer_latency >= 2 && reg1024 && f1024 + owner_bytes(1024) <= LDS_LIMIT && n_chunks >= 64;
+  if (!force_wide && !widest && reg512 && f512 + owner_bytes(512) <= LDS_HALF) {
     plan->variant = V_MID; plan->threads = 512; plan->wgs_per_cu = 2; plan->owner_in_lds = true; plan->source_in_lds = false;
-    plan->lds_bytes = (int)(f512 + owner);
+    plan->lds_bytes = (int)(f512 + owner_bytes(512));
     return true;
   }
-  if (reg1024 && f1024 + owner <= LDS_LIMIT) {
+  if (reg1024 && f1024 + owner_bytes(1024) <= LDS_LIMIT) {
     plan->variant = V_WIDE; plan->threads = 1024; plan->wgs_per_cu = 1; plan->owner_in_lds = true; plan->source_in_lds = false;
-    plan->lds_bytes = (int)(f1024 + owner);
+    plan->lds_bytes = (int)(f1024 + owner_bytes(1024));
     return true;
   }
   const size_t mask = sizeof(unsigned long long) * n_chunks;
