@@ -374,12 +374,14 @@ def main():
     # `frac`, which divides algorithmic bytes by the spec peak and says nothing about where the re-reads are served.
     try:
         import csv
-        so = json.load(open(os.path.join(ROOT, "profiles", "r02_stream_once_pmc_traffic.json")))
-        st = {r["Name"]: float(r["AverageNs"]) for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_stream_once_kernel_stats.csv")))}
+        tag = next(t for t in ("r03_stream_once", "r02_stream_once")
+                   if os.path.exists(os.path.join(ROOT, "profiles", t + "_pmc_traffic.json")))
+        so = json.load(open(os.path.join(ROOT, "profiles", tag + "_pmc_traffic.json")))
+        st = {r["Name"]: float(r["AverageNs"]) for r in csv.DictReader(open(os.path.join(ROOT, "profiles", tag + "_kernel_stats.csv")))}
         for kd in so.get("kernels", []):
             if kd.get("threads") == dom["threads"] and plain_mode and args.storage == "f64" and kd["kernel"] in st:
                 roofline["hbm_only_stream_GBs"] = kd["hbm_bytes_per_launch"] / st[kd["kernel"]]
-                roofline["hbm_only_stream_source"] = ("profiles/r02_stream_once_*: this kernel with one iteration per pair, 8192 pairs "
+                roofline["hbm_only_stream_source"] = (f"profiles/{tag}_*: this kernel with one iteration per pair, 8192 pairs "
                                                       "(6.5 GB pool read once: pure HBM); the timed run's traffic above that rate is "
                                                       "Infinity-Cache hits (DESIGN.md 5.0)")
     except Exception:

@@ -397,6 +397,13 @@ __device__ __forceinline__ void rowcol_from_index(double kd, const RowColFromInd
   cd = fma(-rd, m.w, kd);
 }
 
+// The same for a cursor that may stand in front of the image (negative index): floor instead of trunc.
+__device__ __forceinline__ void rowcol_from_index_floor(double kd, const RowColFromIndex &m, double &cd, double &rd)
+{
+  rd = floor(fma(kd, m.inv_w, m.half_inv_w));
+  cd = fma(-rd, m.w, kd);
+}
+
 // Wave butterfly + cross-wave sum + solve + update + termination, as in gn_level_kernel's tail, for kernels
 // that keep their 27 sums in `acc`.  Returns after the closing barrier; the caller reads s_ctl[CTL_DONE].
 template <int NW>

@@ -112,15 +112,11 @@ __global__ __launch_bounds__(T, T / 256) void gn_level_kernel_slide(const GNLeve
   const bool huber_on = huber_delta > 0.0;
 
   const int k0 = wave * WAVE + lane;
-  const int r0 = k0 / W, c0 = k0 - r0 * W;
-  const int step_r = (NW * WAVE) / W, step_c = (NW * WAVE) - step_r * W;
-  const RowColStep rc_step = make_rowcol_step(step_r, step_c, W);
-  const double cd0 = (double)c0, rd0 = (double)r0;
-  // (row, column) of the pixel (M + 1) bands in front of k0, rows counted downwards from 0 into the negative: where pass 2's
-  // cursor starts; rowcol_advance carries it into the image
-  const int kb = k0 - (SLIDE_M + 1) * SLIDE_BAND_PX;
-  const int rb = -((-kb + W - 1) / W), cb = kb - rb * W;             // floor division for kb < 0
-  const double cd2_0 = (double)cb, rd2_0 = (double)rb;
+  // (row, column) of a cursor's pixel from its linear index, carried as a double (gn_device.hpp, rowcol_from_index_floor:
+  // pass 2's cursor starts (M + 1) bands in front of the image, at negative indices -- rows counted downwards from 0)
+  const RowColFromIndex rc_map = make_rowcol_from_index(W);
+  const double kd_step = (double)(NW * WAVE);
+  const double kd1_0 = (double)k0, kd2_0 = (double)(k0 - (SLIDE_M + 1) * SLIDE_BAND_PX);
 
   int iteration = 0;
   double last_gnorm = 0.0;
@@ -160,9 +156,9 @@ __global__ __launch_bounds__(T, T / 256) void gn_level_kernel_slide(const GNLeve
     // conditional chunk the compiler parks each of them in a temporary, waits for it (s_waitcnt vmcnt(0)) and copies
     // it -- which serialises every chunk behind its own prefetch (measured: 8.0 ms per launch either way, prefetch or not).
     int k1 = k0, j1 = 0;
-    double cd1 = cd0, rd1 = rd0;
+    double kd1 = kd1_0;
     int k2 = k0 - (SLIDE_M + 1) * SLIDE_BAND_PX, j2 = -(SLIDE_M + 1) * B;
-    double cd2 = cd2_0, rd2 = rd2_0;
+    double kd2 = kd2_0;
     // chunk j's "valid and landed in bounds" ballot lives in lane (j & 63) of two registers from pass 1 to pass 2
     int inb_lo = 0, inb_hi = 0;
     int n_rows = 0;                 // Jacobian rows this wave fills in this iteration (popcount of the ballots, scalar unit)
@@ -183,6 +179,8 @@ __global__ __launch_bounds__(T, T / 256) void gn_level_kernel_slide(const GNLeve
     auto pass1_chunk = [&](const int win_lo, const unsigned win_span, double &slot) {
       const double pz = slot;                                           // :279
       slot = plane_load<TD>(rD0, k1 + B * NW * WAVE);                   // this slot's chunk of the next phase (past the plane: 0)
+      double cd1, rd1;
+      rowcol_from_index_floor(kd1, rc_map, cd1, rd1);
       const double px = (cd1 - ox) * pz * ifx;                          // :282
       const double py = (rd1 - oy) * pz * ify;                          // :283
       const double X = fma(r02, pz, fma(r01, py, fma(t15, px, cx)));    // Rt*point3D  :291
@@ -210,7 +208,7 @@ __global__ __launch_bounds__(T, T / 256) void gn_level_kernel_slide(const GNLeve
       inb_hi = writelane_b32(inb_hi, (int)(unsigned)(m >> 32), j1 & 63);
       k1 += NW * WAVE;
       j1++;
-      rowcol_advance(cd1, rd1, rc_step);
+      kd1 += kd_step;
     };
 
     // ---- pass 2 on one chunk: residual, Jacobian row, accumulation  (:308-356, 538-540) -------------------
@@ -230,6 +228,8 @@ __global__ __launch_bounds__(T, T / 256) void gn_level_kernel_slide(const GNLeve
           (unsigned long long)(unsigned)__builtin_amdgcn_readlane(inb_lo, j2 & 63);
       if (__builtin_amdgcn_inverse_ballot_w64(mbits)) {
         const double res = (o >= 0) ? (pixel2 - pixel1) : 0.0;          // :358
+        double cd2, rd2;
+        rowcol_from_index_floor(kd2, rc_map, cd2, rd2);
         const double px = (cd2 - ox) * pz * ifx;
         const double py = (rd2 - oy) * pz * ify;
         // factored Jacobian, derivation in gn_kernels.hip (pass 2)
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(T, T / 256) void gn_level_kernel_slide(const GNLeve
       }
       k2 += NW * WAVE;
       j2++;
-      rowcol_advance(cd2, rd2, rc_step);
+      kd2 += kd_step;
     };
 
     // ---- the phases of this iteration ---------------------------------------------------------------------
