@@ -90,47 +90,51 @@ def capped_launch_work(it, level_sizes, max_iter, min_grad, plane_bytes, iter_ca
     iteration counts the pairs reported -- the schedule of csrc/engine.cpp (phovo_engine_enqueue_align), restated: a level
     with a gradient threshold and max_num_iterations above the cap is a first launch capped at `iter_cap` iterations, then
     (levels of >= 16384 pixels with max_num_iterations > 3 x cap) one capped at 3 x cap and a last one, or (smaller levels)
-    one last launch; with overlapping levels the next level's first launch leaves out the pairs the level before handed
-    over ("marked") and a second first launch takes exactly those.  Order = the order the host enqueues them in (what a
-    rocprofv3 trace lists by Dispatch_Id).  The reference has none of this: one Optimize() loop per pair (...Analytic.h:500-563)."""
+    one last launch.  A pair a capped first launch hands over is MARKED and from then on belongs to the second stream
+    (the long pairs' chain): the first launch of every later level leaves the marked pairs out and a side launch takes
+    exactly those.  Levels whose owner map does not fit LDS (more than 38 828 pixels) end the chain: sliding-window
+    kernel + exact kernel, all pairs.  Order = the order the host enqueues the launches in (what a rocprofv3 trace lists
+    by Dispatch_Id).  The reference has none of this: one Optimize() loop per pair (...Analytic.h:500-563)."""
     iter_cap = int(os.environ.get("PHOVO_GN_ITER_CAP", iter_cap))
     tail_stages = int(os.environ.get("PHOVO_GN_TAIL_STAGES", tail_stages))
     overlap = os.environ.get("PHOVO_GN_OVERLAP", "1") != "0"
     out = []
-    marked = np.zeros(len(it), dtype=bool)          # handed over by the level before, follow-ups possibly still in flight
-    pending = False                                 # the level before runs follow-ups beside this level (the host cannot know
-                                                    # whether any pair was handed over: the launches exist either way)
+    marked = np.zeros(len(it), dtype=bool)          # on the side list: handed over by a capped first launch of an earlier level
+    chain_on = False                                # the second stream runs the marked pairs (the launches exist even if none is)
     levels = [l for l in range(len(max_iter) - 1, -1, -1) if max_iter[l] > 0]
+
+    def chainable(l):
+        return level_sizes[l] <= 38828
     for li, l in enumerate(levels):
         n_it = it[:, l].astype(np.int64)
-        capped = iter_cap > 0 and min_grad[l] > 0.0 and max_iter[l] > iter_cap
 
         def add(name, pair_iterations, pairs):
             out.append(dict(level=l, launch=name, pairs=int(pairs), pair_iterations=int(pair_iterations),
                             algorithmic_bytes=float(plane_bytes * level_sizes[l] * pair_iterations)))
-        first_cap = iter_cap if capped else max_iter[l]
-        first = np.minimum(n_it, first_cap)
-        if pending:
-            add("first, pairs not waiting for the level before", first[~marked].sum(), (~marked).sum())
+        if not chainable(l):
+            chain_on = False
+            add("sliding-window kernel, all pairs (and whatever its exact fallback finishes)", n_it.sum(), len(n_it))
+            add("exact kernel for the pairs that left the window (their iterations are counted in the launch before)", 0, 0)
+            continue
+        capped = iter_cap > 0 and min_grad[l] > 0.0 and max_iter[l] > iter_cap
+        nxt_ok = li + 1 < len(levels) and chainable(levels[li + 1])
+        chain_next = bool(overlap and nxt_ok and (chain_on or capped))
+        first = np.minimum(n_it, iter_cap if capped else max_iter[l])
+        if chain_on:
+            add("first, pairs not on the side list", first[~marked].sum(), (~marked).sum())
+            add("side launch: the pairs handed over at an earlier level", first[marked].sum(), marked.sum())
         else:
             add("first", first.sum(), len(n_it))
-        follow = []
         if capped:
             cap2 = 3 * iter_cap
             if tail_stages >= 3 and max_iter[l] > cap2 and level_sizes[l] >= 16384:
-                mid = np.clip(n_it - iter_cap, 0, cap2 - iter_cap)
-                follow.append((f"follow-up, iterations {iter_cap + 1}..{cap2}", mid.sum(), (n_it > iter_cap).sum()))
-                follow.append((f"follow-up, iterations {cap2 + 1}..", np.maximum(n_it - cap2, 0).sum(), (n_it > cap2).sum()))
+                add(f"follow-up, iterations {iter_cap + 1}..{cap2}", np.clip(n_it - iter_cap, 0, cap2 - iter_cap).sum(), (n_it > iter_cap).sum())
+                add(f"follow-up, iterations {cap2 + 1}..", np.maximum(n_it - cap2, 0).sum(), (n_it > cap2).sum())
             else:
-                follow.append((f"follow-up, iterations {iter_cap + 1}..", np.maximum(n_it - iter_cap, 0).sum(), (n_it > iter_cap).sum()))
-        # host order (engine.cpp): first launch, [second first launch for the marked pairs], then this level's follow-ups
-        if pending:
-            add("first, pairs handed over by the level before", first[marked].sum(), marked.sum())
-        for f in follow:
-            add(*f)
-        nxt_ok = li + 1 < len(levels)
-        pending = bool(capped and overlap and nxt_ok)
-        marked = (n_it > iter_cap) if pending else np.zeros(len(it), dtype=bool)
+                add(f"follow-up, iterations {iter_cap + 1}..", np.maximum(n_it - iter_cap, 0).sum(), (n_it > iter_cap).sum())
+            if chain_next:
+                marked = marked | (n_it > iter_cap)
+        chain_on = chain_next
     return out
 
 

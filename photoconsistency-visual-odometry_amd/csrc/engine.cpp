@@ -58,6 +58,7 @@ struct phovo_engine {
   hipStream_t tail_stream = nullptr;           // the follow-up launches of a capped level, beside the next level's first launch
   hipEvent_t ev_firsts[PHOVO_MAX_LEVELS] = {}, ev_tails[PHOVO_MAX_LEVELS] = {};   // per level: first launch(es) done / follow-ups done
   hipEvent_t ev_total_start = nullptr, ev_total_stop = nullptr;
+  hipEvent_t ev_join = nullptr;                // the second stream's work of an enqueue, for the engine's stream to wait on
   hipEvent_t ev_start[PHOVO_MAX_LEVELS] = {};
   hipEvent_t ev_stop[PHOVO_MAX_LEVELS] = {};
   bool level_launched[PHOVO_MAX_LEVELS] = {};
@@ -104,8 +105,10 @@ struct phovo_engine {
   bool tail_same_plan = false;                 // PHOVO_GN_TAIL_SAME_PLAN=1: second launch with the first one's geometry (A/B, tests)
   bool overlap_levels = true;                  // PHOVO_GN_OVERLAP=0: every launch of an enqueue on ONE stream (A/B, tests)
   int *d_marks = nullptr;                      // [PHOVO_MAX_LEVELS][pairs] "handed over by the level's first launch" (view into d_pairs)
-  int tail_mid_plan = 0;                       // PHOVO_GN_TAIL_MID_PLAN, bit 0: the middle launch of a three-launch level takes the first launch's
-                                               // geometry instead of the latency geometry; bit 1: so does the second launch of a two-launch level
+  int tail_mid_plan = 2;                       // PHOVO_GN_TAIL_MID_PLAN, bit 0: the middle launch of a three-launch level takes the first launch's
+                                               // geometry instead of the latency geometry; bit 1 (default): so does the second launch of a
+                                               // two-launch level -- small workgroups find places beside the next level's first launch, a
+                                               // 1024-thread one needs a whole CU to itself and waits for it (+1..2 % with the shipped thresholds)
   int iter_cap = 4;                            // shipped thresholds, more pairs than workgroup slots: pairs still running after this
                                                // many iterations of a level are finished by a second launch (0 = off)
   int cu_count = 256;
@@ -187,7 +190,7 @@ bool use_wide_level(const phovo_engine *e, int n_pairs, int n_pixels)
 constexpr int HEAD_SETS = 4;
 // Byte offsets of the per-launch pair data for n pairs (see phovo_engine::d_pairs); every section starts 8-byte aligned.
 struct PairLayout {
-  size_t src, tgt, states, reports, heads, handover, handover_stride, marks, marks_stride, total;
+  size_t src, tgt, states, reports, heads, handover, handover_stride, marks, marks_stride, side, total;
 };
 PairLayout pair_layout(int n_pairs)
 {
@@ -203,7 +206,9 @@ PairLayout pair_layout(int n_pairs)
   l.handover_stride = n2 + 2;                   // ints per level: the list of handed-over pairs and, at [n_pairs], its length
   l.marks = l.handover + sizeof(int) * l.handover_stride * 2 * PHOVO_MAX_LEVELS;       // two lists per level
   l.marks_stride = n2;                          // ints per level: 1 = handed over by the level's first launch
-  l.total = l.marks + sizeof(int) * l.marks_stride * PHOVO_MAX_LEVELS;
+  // the cumulative side list of the long pairs' chain (enqueue): [n2 + 2] like a hand-over list, then one count snapshot per level
+  l.side = l.marks + sizeof(int) * l.marks_stride * PHOVO_MAX_LEVELS;
+  l.total = l.side + sizeof(int) * (l.handover_stride + PHOVO_MAX_LEVELS);
   return l;
 }
 
@@ -441,6 +446,7 @@ int phovo_engine_create(int device, phovo_engine **out)
   if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->tail_stream, hipStreamNonBlocking);
   if (he == hipSuccess) he = hipEventCreate(&e->ev_total_start);
   if (he == hipSuccess) he = hipEventCreate(&e->ev_total_stop);
+  if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
   for (int l = 0; l < PHOVO_MAX_LEVELS && he == hipSuccess; l++) {
     he = hipEventCreateWithFlags(&e->ev_firsts[l], hipEventDisableTiming);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_tails[l], hipEventDisableTiming);
@@ -498,6 +504,7 @@ int phovo_engine_destroy(phovo_engine *e)
   }
   if (e->ev_total_start) (void)hipEventDestroy(e->ev_total_start);
   if (e->ev_total_stop) (void)hipEventDestroy(e->ev_total_stop);
+  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
   if (e->tail_stream) (void)hipStreamDestroy(e->tail_stream);
   if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -1012,32 +1019,48 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
   PHOVO_HIP_CHECK(hipMemsetAsync(e->d_pairs + pl.reports, 0, pl.total - pl.reports, e->stream));
   PHOVO_HIP_CHECK(hipEventRecord(e->ev_total_start, e->stream));
 
-  // Overlap of consecutive levels (shipped thresholds).  A capped level ends with one or two launches that hold a few
-  // per cent of the pairs -- the long ones -- and leave most CUs idle (80x60, 8192 pairs: 0.33 of 1.1 ms).  Pairs are
-  // independent, so those follow-up launches go to a SECOND stream while the next level's first launch, on the
-  // engine's stream, already takes every pair that is not waiting for them (the first launch of a level marks the
-  // pairs it hands over; the next level's draws pass marked pairs by); a second "first launch" of the next level then
-  // takes the marked pairs from the hand-over list once the follow-ups have finished.  Same kernels, same geometries,
-  // same arithmetic per pair as on one stream: only the order in time changes (PHOVO_GN_OVERLAP=0: A/B, tests).
-  struct Pending { bool on = false; const int *list = nullptr; const int *marks = nullptr; hipEvent_t done = nullptr; };
-  Pending pending;                         // the level before: follow-ups in flight on tail_stream
-  auto join_pending = [&]() -> hipError_t {            // nothing of this enqueue is in flight on tail_stream any more (for e->stream)
-    if (!pending.on) return hipSuccess;
-    pending.on = false;
-    return hipStreamWaitEvent(e->stream, pending.done, 0);
+  // The long pairs' own chain (shipped thresholds).  A capped level ends with one or two launches that hold a few per
+  // cent of the pairs -- the long ones -- and leave most CUs idle (80x60, 8192 pairs: 0.33 of 1.1 ms), and the next
+  // level's share of those pairs is another launch of a few hundred workgroups.  Pairs are independent, so ALL of that runs
+  // on a SECOND stream, beside the first launches of the following levels on the engine's stream:
+  //   * the first launch of a capped level MARKS every pair it hands over and appends it, once, to a cumulative side list;
+  //   * from then on a marked pair belongs to the second stream: the first launch of every later level passes marked
+  //     pairs by (draw_pair_any), and a "side" first launch on the second stream takes the side list -- the prefix of it
+  //     that existed when the level before had been dealt out (a count snapshot taken on the engine's stream; newer
+  //     entries are pairs this very level hands over, and those belong to its follow-up launches);
+  //   * the follow-up launches of a level go to the second stream too, behind the side launch (stream order) and behind
+  //     the engine stream's first launch (event).
+  // The engine's stream never waits for the second one before the end of the enqueue.  Same kernels, same geometries,
+  // same arithmetic per pair and level as on one stream -- which launch runs a pair's level depends on the level's size
+  // and on the pair's own iteration counts only -- so results are bit-identical with and without
+  // (PHOVO_GN_OVERLAP=0: everything on ONE stream; tests/test_gpu_round3.py compares the two).
+  const PairLayout lay = pair_layout(n_pairs);
+  int *const marks = e->d_marks;                                           // [pairs] 1 = on the side list
+  int *const side_list = reinterpret_cast<int *>(e->d_pairs + lay.side);   // [pairs] + count at [n_pairs]
+  int *const side_snap = side_list + lay.handover_stride;                  // [PHOVO_MAX_LEVELS] count snapshots, one per level
+  bool chain_on = false;          // marked pairs may exist: first launches pass them by, the second stream runs them
+  bool tail_dirty = false;        // the second stream holds work of this enqueue that the engine's stream has not waited for
+  int prev_level = -1;            // the level whose first launch (and snapshot) ev_firsts[prev_level] stands for
+  auto join_tail = [&]() -> hipError_t {
+    if (!tail_dirty) return hipSuccess;
+    tail_dirty = false;
+    hipError_t he = hipEventRecord(e->ev_join, e->tail_stream);
+    if (he != hipSuccess) return he;
+    return hipStreamWaitEvent(e->stream, e->ev_join, 0);
   };
-  // the next level that will run, and whether its first launch can take part in an overlap (persistent kernel, owner map in LDS)
-  auto next_overlappable = [&](int l) {
-    for (int m = l - 1; m >= 0; m--) {
-      if (e->cfg.max_num_iterations[m] <= 0) continue;
-      const LevelPool &nx = e->levels[m];
-      if (e->ext.sampling == PHOVO_SAMPLING_BILINEAR) return false;
-      if (use_wide_level(e, n_pairs, nx.n) && !(e->ext.huber_delta[m] > 0.0)) return false;
-      const bool few_m = !e->batch_invariant && n_pairs <= LATENCY_PAIRS && nx.plan_few_ok &&
-                         nx.plan_few.owner_in_lds == nx.plan.owner_in_lds;
-      return (few_m ? nx.plan_few : nx.plan).owner_in_lds;
-    }
-    return false;
+  // does level m run the persistent kernel with its owner map in LDS (the only form that takes part)?
+  auto chainable = [&](int m) {
+    const LevelPool &nx = e->levels[m];
+    if (e->ext.sampling == PHOVO_SAMPLING_BILINEAR) return false;
+    if (use_wide_level(e, n_pairs, nx.n) && !(e->ext.huber_delta[m] > 0.0)) return false;
+    const bool few_m = !e->batch_invariant && n_pairs <= LATENCY_PAIRS && nx.plan_few_ok &&
+                       nx.plan_few.owner_in_lds == nx.plan.owner_in_lds;
+    return (few_m ? nx.plan_few : nx.plan).owner_in_lds;
+  };
+  auto next_active = [&](int l) {
+    for (int m = l - 1; m >= 0; m--)
+      if (e->cfg.max_num_iterations[m] > 0) return m;
+    return -1;
   };
 
   for (int l = e->cfg.num_levels - 1; l >= 0; l--) {                                 // coarse to fine  :502-503
@@ -1068,11 +1091,13 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
     static const bool single_queue = std::getenv("PHOVO_QUEUE_SINGLE") != nullptr;
     a.n_queues = (!single_queue && n_pairs >= 8 * 64) ? QUEUES_PER_LEVEL : 1;
     PHOVO_HIP_CHECK(hipEventRecord(e->ev_start[l], e->stream));
+    if (!chainable(l)) {                     // this level takes all pairs in one form on the engine's stream: the chain ends
+      PHOVO_HIP_CHECK(join_tail());
+      chain_on = false;
+    }
     if (e->ext.sampling == PHOVO_SAMPLING_BILINEAR) {
-      PHOVO_HIP_CHECK(join_pending());
       PHOVO_HIP_CHECK(gn_launch_level_bilinear(a, e->ext.plane_storage, e->ext.jacobian_corrected != 0, e->cu_count, e->stream));
     } else if (use_wide_level(e, n_pairs, lv.n) && !(e->ext.huber_delta[l] > 0.0)) {
-      PHOVO_HIP_CHECK(join_pending());
       if (e->owner_tagged) {            // the wide form starts from -1 everywhere and leaves it so
         PHOVO_HIP_CHECK(fill_i32(e->d_owner, e->owner_capacity, -1, e->stream));
         e->owner_tagged = false;
@@ -1084,27 +1109,11 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
                        lv.plan_few.owner_in_lds == lv.plan.owner_in_lds;
       const GNLaunchPlan &pl = few ? lv.plan_few : lv.plan;
       a.n_lds = pl.owner_in_lds ? 0 : pl.owner_lds_entries;
-      const size_t hstride = pair_layout(n_pairs).handover_stride;
+      const size_t hstride = lay.handover_stride;
       int *list0 = e->d_handover + (size_t)(2 * l) * hstride, *list1 = list0 + hstride;
       int *heads1 = e->d_work_counters + (PHOVO_MAX_LEVELS + l) * QUEUES_PER_LEVEL;
       int *heads2 = e->d_work_counters + (2 * PHOVO_MAX_LEVELS + l) * QUEUES_PER_LEVEL;
       int *heads3 = e->d_work_counters + (3 * PHOVO_MAX_LEVELS + l) * QUEUES_PER_LEVEL;
-      int *marks = e->d_marks + (size_t)l * pair_layout(n_pairs).marks_stride;
-      if (!pl.owner_in_lds) PHOVO_HIP_CHECK(join_pending());     // (only levels with the owner map in LDS take part in an overlap)
-      // The first launch of this level: all pairs -- or, while the level before still finishes its long pairs on the
-      // second stream, first the pairs that are not waiting for that and then, behind it, the ones that were.
-      auto first_launches = [&](GNLevelArgs f) -> hipError_t {
-        hipError_t he;
-        if (pending.on) f.skip_marks = pending.marks;
-        if ((he = gn_launch_level(f, pl, e->ext.plane_storage, e->cu_count, e->stream)) != hipSuccess) return he;
-        if (pending.on) {
-          f.skip_marks = nullptr; f.handover_in = pending.list; f.takeover_flag = 0;
-          f.work_counter = heads3; f.n_queues = 1;
-          if ((he = join_pending()) != hipSuccess) return he;
-          if ((he = gn_launch_level(f, pl, e->ext.plane_storage, e->cu_count, e->stream)) != hipSuccess) return he;
-        }
-        return hipSuccess;
-      };
       if (!pl.owner_in_lds && e->slide_policy >= 0) {
         // Owner map too large for LDS: the sliding-window kernel first (owner ring in LDS); pairs whose warp leaves its
         // window are put on the hand-over list and continued, from the iteration they had reached, by the exact kernel
@@ -1113,70 +1122,87 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
         PHOVO_HIP_CHECK(gn_launch_level_slide(a, e->ext.plane_storage, e->cu_count, e->stream));
         a.handover_out = nullptr; a.handover_in = list0; a.takeover_flag = PHOVO_PAIR_WINDOW_FALLBACK;
         a.work_counter = heads1; a.n_queues = 1;
-      } else if (e->iter_cap > 0 && a.min_grad_norm > 0.0 && a.max_iter > e->iter_cap && !few) {
-        // Data-dependent termination: most pairs stop after a few iterations, a few run to max_num_iterations, and
-        // whichever of those a workgroup draws late finishes alone on its CU long after the queue is empty (the launch
-        // then ends with one pair per CU at that CU's own fp64 rate).  So the first launch caps every pair at iter_cap
-        // iterations and hands the unfinished ones over; the second starts all of them at once, each from its stored
-        // state and iteration count, in the geometry that runs one pair fastest, and (where max_num_iterations allows)
-        // caps them again at 3 x iter_cap for a third launch -- pairs of one launch then need about the same number
-        // of iterations and finish together.  Every batch the persistent kernel takes in its throughput geometry goes
-        // this way; with batch_invariant that is EVERY batch, so that a pair's result does not depend on how many other
-        // pairs were aligned with it (a sequence gives the same trajectory file, byte for byte, however it is cut into
-        // shards: tests/test_sequence_sharded.py).
-        a.handover_out = list0; a.iter_cap = e->iter_cap;
-        // the follow-ups of THIS level beside the next level's first launch?
-        const bool overlap = e->overlap_levels && next_overlappable(l);
-        if (overlap) a.mark_out = marks;
-        PHOVO_HIP_CHECK(first_launches(a));
-        a.mark_out = nullptr;
-        hipStream_t ts = e->stream;
-        if (overlap) {
-          ts = e->tail_stream;
-          PHOVO_HIP_CHECK(hipEventRecord(e->ev_firsts[l], e->stream));
-          PHOVO_HIP_CHECK(hipStreamWaitEvent(ts, e->ev_firsts[l], 0));
-        }
-        const GNLaunchPlan &tail = (!e->tail_same_plan && lv.plan_tail_ok && lv.plan_tail.owner_in_lds) ? lv.plan_tail : pl;
-        // The launch right behind the first one still has MANY pairs (6 % of the batch in the bench: two per CU at 8192
-        // pairs): it keeps the first launch's geometry, several workgroups per CU, so that all of them start at once; the
-        // last launch has about one pair per CU and takes the geometry that runs one pair fastest.  (Which geometry a
-        // launch takes depends on the level only, never on the batch size: see batch_invariant.)
-        const GNLaunchPlan &mid = (e->tail_mid_plan & 1) ? pl : tail;
-        a.takeover_flag = 0; a.n_queues = 1;
-        const int cap2 = 3 * e->iter_cap;
-        // (a third launch pays on the larger levels: 160x120, 8192 pairs 3.85 -> 3.63 ms; on 80x60 its fixed cost is
-        // larger than what the better balance returns)
-        if (e->tail_stages >= 3 && a.max_iter > cap2 && lv.n >= 16384) {
-          a.handover_in = list0; a.handover_out = list1; a.iter_cap = cap2; a.work_counter = heads1;
-          PHOVO_HIP_CHECK(gn_launch_level(a, mid, e->ext.plane_storage, e->cu_count, ts));
-          a.handover_in = list1; a.work_counter = heads2;
-          a.handover_out = nullptr; a.iter_cap = 0;
-          PHOVO_HIP_CHECK(gn_launch_level(a, tail, e->ext.plane_storage, e->cu_count, ts));
-        } else {
-          // two launches: the second one is "the launch right behind the first" and the last at once
-          a.handover_in = list0; a.work_counter = heads1;
-          a.handover_out = nullptr; a.iter_cap = 0;
-          PHOVO_HIP_CHECK(gn_launch_level(a, (e->tail_mid_plan & 2) ? pl : tail, e->ext.plane_storage, e->cu_count, ts));
-        }
-        PHOVO_HIP_CHECK(hipEventRecord(e->ev_stop[l], ts));       // (the level's span ends with its last follow-up, on whichever stream)
-        if (overlap) {
-          PHOVO_HIP_CHECK(hipEventRecord(e->ev_tails[l], ts));
-          pending.on = true; pending.list = list0; pending.marks = marks; pending.done = e->ev_tails[l];
-        }
-        e->level_launched[l] = true;
-        continue;
-      }
-      if (pl.owner_in_lds) {
-        PHOVO_HIP_CHECK(first_launches(a));                  // one launch (no cap on this level): all pairs, or the two halves
-      } else {
         PHOVO_HIP_CHECK(gn_launch_level(a, pl, e->ext.plane_storage, e->cu_count, e->stream));
         e->owner_tagged = true;                              // tagged entries stay behind (the kernel wipes per pair)
+      } else if (!pl.owner_in_lds) {
+        PHOVO_HIP_CHECK(gn_launch_level(a, pl, e->ext.plane_storage, e->cu_count, e->stream));
+        e->owner_tagged = true;
+      } else {
+        // Data-dependent termination: most pairs stop after a few iterations, a few run to max_num_iterations, and
+        // whichever of those a workgroup draws late finishes alone on its CU long after the queue is empty (the launch
+        // then ends with one pair per CU at that CU's own fp64 rate).  So the first launch of such a level CAPS every pair
+        // at iter_cap iterations and hands the unfinished ones over; a follow-up launch starts all of them at once, each
+        // from its stored state and iteration count, in the geometry that runs one pair fastest, and (where
+        // max_num_iterations allows) caps them again at 3 x iter_cap for a third launch -- pairs of one launch then need
+        // about the same number of iterations and finish together.  Every batch the persistent kernel takes in its
+        // throughput geometry goes this way; with batch_invariant that is EVERY batch, so that a pair's result does not
+        // depend on how many other pairs were aligned with it (a sequence gives the same trajectory file, byte for byte,
+        // however it is cut into shards: tests/test_sequence_sharded.py).
+        const bool capped = e->iter_cap > 0 && a.min_grad_norm > 0.0 && a.max_iter > e->iter_cap && !few;
+        const int nxt = next_active(l);
+        // does the long pairs' chain start here or go on below this level?
+        const bool chain_next = e->overlap_levels && nxt >= 0 && chainable(nxt) && (chain_on || capped);
+        GNLevelArgs f = a;                                   // the first launch(es) of the level
+        if (capped) { f.handover_out = list0; f.iter_cap = e->iter_cap; }
+        if (capped && chain_next) { f.mark_out = marks; f.side_out = side_list; }
+        GNLevelArgs fs = f;                                  // ... its side launch: the marked pairs, on the second stream
+        if (chain_on) f.skip_marks = marks;
+        PHOVO_HIP_CHECK(gn_launch_level(f, pl, e->ext.plane_storage, e->cu_count, e->stream));
+        if (chain_next)                                      // what is on the side list NOW is what the next level's side launch takes
+          PHOVO_HIP_CHECK(hipMemcpyAsync(side_snap + nxt, side_list + n_pairs, sizeof(int), hipMemcpyDeviceToDevice, e->stream));
+        if (chain_on) {
+          // (behind the launches of the level before that these pairs wait for: stream order; and behind the snapshot)
+          PHOVO_HIP_CHECK(hipStreamWaitEvent(e->tail_stream, e->ev_firsts[prev_level], 0));
+          fs.handover_in = side_list; fs.handover_count = side_snap + l; fs.takeover_flag = 0;
+          fs.work_counter = heads3; fs.n_queues = 1;
+          PHOVO_HIP_CHECK(gn_launch_level(fs, pl, e->ext.plane_storage, e->cu_count, e->tail_stream));
+          tail_dirty = true;
+        }
+        hipStream_t ts = e->stream;                          // where this level's follow-ups go
+        if (chain_next) {
+          PHOVO_HIP_CHECK(hipEventRecord(e->ev_firsts[l], e->stream));
+          prev_level = l;
+          ts = e->tail_stream;
+        } else {
+          PHOVO_HIP_CHECK(join_tail());                      // the chain ends with this level: its side launch first
+        }
+        if (capped) {
+          if (ts == e->tail_stream) {
+            PHOVO_HIP_CHECK(hipStreamWaitEvent(ts, e->ev_firsts[l], 0));
+            tail_dirty = true;
+          }
+          const GNLaunchPlan &tail = (!e->tail_same_plan && lv.plan_tail_ok && lv.plan_tail.owner_in_lds) ? lv.plan_tail : pl;
+          // (which geometry a launch takes depends on the level only, never on the batch size: see batch_invariant;
+          // PHOVO_GN_TAIL_MID_PLAN: A/B of the first launch's geometry for the follow-ups, +-0.5 % either way)
+          const GNLaunchPlan &mid = (e->tail_mid_plan & 1) ? pl : tail;
+          GNLevelArgs u = a;
+          u.takeover_flag = 0; u.n_queues = 1;
+          const int cap2 = 3 * e->iter_cap;
+          // (a third launch pays on the larger levels: 160x120, 8192 pairs 3.85 -> 3.63 ms; on 80x60 its fixed cost is
+          // larger than what the better balance returns)
+          if (e->tail_stages >= 3 && a.max_iter > cap2 && lv.n >= 16384) {
+            u.handover_in = list0; u.handover_out = list1; u.iter_cap = cap2; u.work_counter = heads1;
+            PHOVO_HIP_CHECK(gn_launch_level(u, mid, e->ext.plane_storage, e->cu_count, ts));
+            u.handover_in = list1; u.work_counter = heads2;
+            u.handover_out = nullptr; u.iter_cap = 0;
+            PHOVO_HIP_CHECK(gn_launch_level(u, tail, e->ext.plane_storage, e->cu_count, ts));
+          } else {
+            // two launches: the second one is "the launch right behind the first" and the last at once
+            u.handover_in = list0; u.work_counter = heads1;
+            u.handover_out = nullptr; u.iter_cap = 0;
+            PHOVO_HIP_CHECK(gn_launch_level(u, (e->tail_mid_plan & 2) ? pl : tail, e->ext.plane_storage, e->cu_count, ts));
+          }
+        }
+        chain_on = chain_next;
+        PHOVO_HIP_CHECK(hipEventRecord(e->ev_stop[l], ts));       // (the level's span ends with its last launch, on whichever stream)
+        e->level_launched[l] = true;
+        continue;
       }
     }
     PHOVO_HIP_CHECK(hipEventRecord(e->ev_stop[l], e->stream));
     e->level_launched[l] = true;
   }
-  PHOVO_HIP_CHECK(join_pending());
+  PHOVO_HIP_CHECK(join_tail());
   PHOVO_HIP_CHECK(hipEventRecord(e->ev_total_stop, e->stream));
   e->have_timing = true;
   return PHOVO_OK;

@@ -328,7 +328,8 @@ __device__ __forceinline__ int draw_pair_any(const GNLevelArgs &A)
     }
     return p;
   }
-  const int count = __hip_atomic_load(&A.handover_in[A.n_pairs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int count = __hip_atomic_load(A.handover_count ? A.handover_count : &A.handover_in[A.n_pairs], __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT);
   const int i = atomicAdd(A.work_counter, 1);
   return i < count ? __hip_atomic_load(&A.handover_in[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : A.n_pairs;
 }
@@ -339,7 +340,10 @@ __device__ __forceinline__ void handover_append(const GNLevelArgs &A, int pair)
 {
   const int slot = atomicAdd(&A.handover_out[A.n_pairs], 1);
   A.handover_out[slot] = pair;
-  if (A.mark_out) A.mark_out[pair] = 1;
+  if (A.mark_out && atomicExch(&A.mark_out[pair], 1) == 0 && A.side_out) {       // marked for the first time: onto the side list
+    const int s = atomicAdd(&A.side_out[A.n_pairs], 1);
+    A.side_out[s] = pair;
+  }
 }
 
 // v_writelane_b32: lane `lane` (wave-uniform) of `old` becomes `value` (wave-uniform); the other lanes keep theirs.

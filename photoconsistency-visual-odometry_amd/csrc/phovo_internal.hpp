@@ -50,13 +50,19 @@ struct GNLevelArgs {
   int *handover_out;
   int iter_cap;
   unsigned takeover_flag;
-  // Levels that overlap (engine.cpp, enqueue): while the launches that finish the long pairs of the level before still run
-  // on a second stream, the first launch of this level takes every pair that is NOT waiting for them.
+  // The long pairs' chain (engine.cpp, enqueue): a pair a capped first launch hands over is MARKED and from then on runs on
+  // a second stream, beside the first launches of the later levels on the engine's stream.
   //   mark_out    non-null: a pair appended to handover_out also gets mark_out[pair] = 1 (zeroed per enqueue)
   //   skip_marks  non-null (plain queue only): a drawn pair with skip_marks[pair] != 0 is not this launch's -- it is
-  //               drawn past (a later launch takes the marked pairs from the hand-over list they are on)
+  //               drawn past (the side launch of the level takes the marked pairs from the cumulative side list)
+  //   side_out    non-null, with mark_out: a pair that gets its mark for the FIRST time is also appended to this cumulative
+  //               list (pair indices, number at [n_pairs]) -- the pairs the second stream runs from the next level on
+  //   handover_count  non-null, with handover_in: the launch takes that many entries of the list (a snapshot taken on
+  //               the stream earlier) instead of its current length at [n_pairs]
   int *mark_out;
   const int *skip_marks;
+  int *side_out;
+  const int *handover_count;
 };
 
 constexpr int QUEUES_PER_LEVEL = 8;      // one per XCD

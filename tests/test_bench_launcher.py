@@ -128,6 +128,9 @@ def test_per_launch_work_accounting_conserves_the_pair_iterations():
     assert [w["level"] for w in serial] == [4, 4, 3, 3, 2, 2]
     l3 = [w for w in work if w["level"] == 3]
     assert l3[0]["pairs"] + l3[1]["pairs"] == 1000 and l3[1]["pairs"] == int((it[:, 4] > 4).sum())
+    # the side list is cumulative: level 2's side launch takes what level 4 AND level 3 handed over
+    l2 = [w for w in work if w["level"] == 2]
+    assert l2[1]["pairs"] == int(((it[:, 4] > 4) | (it[:, 3] > 4)).sum()) and l2[0]["pairs"] + l2[1]["pairs"] == 1000
     # a level of >= 16384 pixels whose max_num_iterations exceeds 3 x cap gets three launches (the 4-level configuration)
     four = bench.capped_launch_work(it[:, :4], sizes[:4], [0, 0, 20, 50], min_grad[:4], 40.0)
     assert [w["level"] for w in four] == [3, 3, 2, 2, 2, 2]

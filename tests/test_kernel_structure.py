@@ -106,13 +106,14 @@ def test_two_draws_from_the_queue(kernels):
         # two draw sites (before the loop, in the write-back block), each with the single-queue add and the per-XCD-queue
         # add of draw_pair; gn_level_kernel can also take its pairs from a hand-over list (a third add per site), draw past
         # pairs that are marked as another launch's (draw_pair once more, inside that loop: two more adds per site) and,
-        # like the sliding-window kernel, append to a hand-over list (one add, in the write-back block)
+        # like the sliding-window kernel, append to a hand-over list (one add, in the write-back block) -- and, a pair marked
+        # for the first time, to the cumulative side list of the long pairs' chain (one more)
         if "gn_level_kernel_slide" in name:
-            want = 2 * 2 + 1
+            want = 2 * 2 + 2
         elif "gn_level_kernel_bilinear" in name:
             want = 2 * 2
         else:
-            want = 2 * 5 + 1
+            want = 2 * 5 + 2
         assert n == want, f"{name}: {n} atomic adds, expected {want}"
 
 
