@@ -559,7 +559,10 @@ def main():
                 "pairs_per_gpu": n_local, "global_pairs_per_step": n_global,
                 "distinct_pairs_per_gpu": distinct, "image": [W, H], "levels": nl,
                 "max_num_iterations": max_iter, "max_num_iterations_overridden": bool(args.max_iterations),
-                "parallelism": f"pairs sharded x{world}, RCCL all_gather of states",
+                "parallelism": f"pairs sharded x{world}, "
+                               + ("RCCL" if os.environ.get("PHOVO_BENCH_BACKEND", "nccl") == "nccl" else
+                                  os.environ["PHOVO_BENCH_BACKEND"] + " (rehearsal backend, not RCCL)")
+                               + " all_gather of states",
                 "all_gather_from_device_buffer": ZERO_COPY["ok"],
             },
             "iterations_per_pair": [float(x) for x in iters.mean(axis=0)],

@@ -98,7 +98,7 @@ struct phovo_engine {
   int *d_owner = nullptr;
   size_t owner_capacity = 0;
   bool owner_tagged = false;                   // d_owner holds tagged entries of the persistent kernel, not the -1 the wide form expects
-  int *d_work_counters = nullptr;              // [2][PHOVO_MAX_LEVELS][QUEUES_PER_LEVEL] work-queue heads of the level launches (view into d_pairs)
+  int *d_work_counters = nullptr;              // [4][PHOVO_MAX_LEVELS][QUEUES_PER_LEVEL x QUEUE_HEAD_STRIDE] work-queue heads of the level launches (view into d_pairs)
   int *d_handover = nullptr;                   // [PHOVO_MAX_LEVELS][pairs + 2] hand-over lists of the two-launch levels (view into d_pairs)
   int slide_policy = 0;                        // 0 automatic (where the owner map exceeds LDS), -1 never
   int tail_stages = 3;                         // launches of a capped level: 3 = caps at iter_cap and 3 x iter_cap (PHOVO_GN_TAIL_STAGES=2: one cap)
@@ -202,7 +202,7 @@ PairLayout pair_layout(int n_pairs)
   l.reports = l.states + sizeof(double) * 6 * (size_t)n_pairs;
   l.heads = l.reports + sizeof(phovo_pair_report) * (size_t)n_pairs;
   // four sets of heads per level: every launch of a level (up to four, see enqueue) drains its own queue
-  l.handover = l.heads + sizeof(int) * HEAD_SETS * PHOVO_MAX_LEVELS * QUEUES_PER_LEVEL;
+  l.handover = l.heads + sizeof(int) * HEAD_SETS * PHOVO_MAX_LEVELS * QUEUE_HEADS_INTS;
   l.handover_stride = n2 + 2;                   // ints per level: the list of handed-over pairs and, at [n_pairs], its length
   l.marks = l.handover + sizeof(int) * l.handover_stride * 2 * PHOVO_MAX_LEVELS;       // two lists per level
   l.marks_stride = n2;                          // ints per level: 1 = handed over by the level's first launch
@@ -1085,7 +1085,7 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
     a.states = e->d_states; a.reports = e->d_reports;
     a.g_owner = e->d_owner;
     a.n_pairs = n_pairs;
-    a.work_counter = e->d_work_counters + l * QUEUES_PER_LEVEL;
+    a.work_counter = e->d_work_counters + l * QUEUE_HEADS_INTS;
     // one queue per XCD once there are enough pairs to keep every XCD's share of the grid busy; PHOVO_QUEUE_SINGLE=1
     // is a tuning aid for tools/ (A/B of the placement)
     static const bool single_queue = std::getenv("PHOVO_QUEUE_SINGLE") != nullptr;
@@ -1111,9 +1111,9 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
       a.n_lds = pl.owner_in_lds ? 0 : pl.owner_lds_entries;
       const size_t hstride = lay.handover_stride;
       int *list0 = e->d_handover + (size_t)(2 * l) * hstride, *list1 = list0 + hstride;
-      int *heads1 = e->d_work_counters + (PHOVO_MAX_LEVELS + l) * QUEUES_PER_LEVEL;
-      int *heads2 = e->d_work_counters + (2 * PHOVO_MAX_LEVELS + l) * QUEUES_PER_LEVEL;
-      int *heads3 = e->d_work_counters + (3 * PHOVO_MAX_LEVELS + l) * QUEUES_PER_LEVEL;
+      int *heads1 = e->d_work_counters + (PHOVO_MAX_LEVELS + l) * QUEUE_HEADS_INTS;
+      int *heads2 = e->d_work_counters + (2 * PHOVO_MAX_LEVELS + l) * QUEUE_HEADS_INTS;
+      int *heads3 = e->d_work_counters + (3 * PHOVO_MAX_LEVELS + l) * QUEUE_HEADS_INTS;
       if (!pl.owner_in_lds && e->slide_policy >= 0) {
         // Owner map too large for LDS: the sliding-window kernel first (owner ring in LDS); pairs whose warp leaves its
         // window are put on the hand-over list and continued, from the iteration they had reached, by the exact kernel

@@ -34,7 +34,7 @@ struct GNLevelArgs {
   phovo_pair_report *reports;   // [pairs]
   int *g_owner;             // [pairs][n] owner map in global memory (only when it does not fit LDS)
   int n_pairs;              // pairs of this launch
-  int *work_counter;        // [QUEUES_PER_LEVEL] heads, zeroed before the launch: workgroups draw pair indices from them
+  int *work_counter;        // [QUEUES_PER_LEVEL] heads QUEUE_HEAD_STRIDE ints apart, zeroed before the launch: workgroups draw pair indices from them
   int n_queues;             // 1: one queue for the whole grid; 8: one per XCD over a contiguous eighth of the pairs (+ stealing)
   int n_lds;                // owner map in HBM only: its first n_lds entries (a multiple of 64) live in LDS instead
   // Hand-over of unfinished pairs from one launch of a level to the next (all on the same stream).  A list is
@@ -66,6 +66,8 @@ struct GNLevelArgs {
 };
 
 constexpr int QUEUES_PER_LEVEL = 8;      // one per XCD
+constexpr int QUEUE_HEAD_STRIDE = 32;    // ints between two queue heads: a 128-byte line each (the draws are atomics, served per line)
+constexpr int QUEUE_HEADS_INTS = QUEUES_PER_LEVEL * QUEUE_HEAD_STRIDE;     // the heads of one launch
 
 struct GNLaunchPlan {
   int variant;              // which instantiation of the level kernel (gn_kernels.hip)

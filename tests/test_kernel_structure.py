@@ -103,17 +103,17 @@ def test_every_barrier_waits_for_lds_first():
 def test_two_draws_from_the_queue(kernels):
     for name, body in kernels.items():
         n = sum("global_atomic_add" in l for l in body)
-        # two draw sites (before the loop, in the write-back block), each with the single-queue add and the per-XCD-queue
-        # add of draw_pair; gn_level_kernel can also take its pairs from a hand-over list (a third add per site), draw past
-        # pairs that are marked as another launch's (draw_pair once more, inside that loop: two more adds per site) and,
-        # like the sliding-window kernel, append to a hand-over list (one add, in the write-back block) -- and, a pair marked
-        # for the first time, to the cumulative side list of the long pairs' chain (one more)
+        # two draw sites (before the loop, in the write-back block), each with ONE add in draw_pair (the queue heads sit a
+        # cache line apart; a single queue is queue 0 of eight); gn_level_kernel can also take its pairs from a hand-over
+        # list (a second add per site) and draw past pairs that are marked as another launch's (draw_pair once more, inside
+        # that loop: a third) and, like the sliding-window kernel, append to a hand-over list (one add, in the write-back
+        # block) -- and, a pair marked for the first time, to the cumulative side list of the long pairs' chain (one more)
         if "gn_level_kernel_slide" in name:
-            want = 2 * 2 + 2
+            want = 2 * 1 + 2
         elif "gn_level_kernel_bilinear" in name:
-            want = 2 * 2
+            want = 2 * 1
         else:
-            want = 2 * 5 + 2
+            want = 2 * 3 + 2
         assert n == want, f"{name}: {n} atomic adds, expected {want}"
 
 

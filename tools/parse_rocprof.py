@@ -1,6 +1,6 @@
 """Turns the rocprofv3 outputs of one profiling session into the files kept under profiles/:
 
-    python tools/parse_rocprof.py gpurun_out/prof_r01 profiles r01 [--current] [--pairs 8192]
+    python tools/parse_rocprof.py gpurun_out/prof_r01 profiles r01 [--current] [--pairs 8192] [--calibration profiles/<tag>_pmc_traffic.json]
 
 --pairs is the number of frame pairs each profiled launch aligned (bench.py --pairs): the level kernels draw pairs
 from a work queue, so the grid size no longer says how many there were.
@@ -90,6 +90,12 @@ def main():
         cal[name] = dict(counter_KB=vals[0] if vals else None, known_bytes=known,
                          factor=(known / (vals[0] * 1024.0)) if vals and vals[0] > 0 else None)
 
+    # a session whose calibration passes were skipped (PROFILE_SKIP_CAL=1) takes the factors of the session named by
+    # --calibration <its *_pmc_traffic.json> (same box, same call: tools/profile_r03.sh)
+    if "--calibration" in sys.argv and not (cal["FETCH_SIZE"]["factor"] and cal["WRITE_SIZE"]["factor"]):
+        ref = sys.argv[sys.argv.index("--calibration") + 1]
+        cal = json.load(open(ref))["calibration"]
+        cal["taken_from"] = os.path.basename(ref)
     out = dict(tag=tag, calibration=cal, kernels=[])
     fetch, nf = mean_by_kernel(counter_rows(os.path.join(src, "pmc_fetch")), skip_first=2)
     write, _ = mean_by_kernel(counter_rows(os.path.join(src, "pmc_write")), skip_first=2)
