@@ -228,8 +228,11 @@ int phovo_engine_set_slide_policy(phovo_engine *e, int policy);
  * phovo_engine_set_batch_invariant every batch) runs as two or three launches: every pair for at most `cap` iterations,
  * then the pairs still running, all started together, to their end (the few long pairs otherwise finish one per CU
  * after the queue is empty).  Default 4; 0 = one launch.  Iteration counts are identical either way and poses agree
- * within the parity bar; the later launches use the geometry that runs ONE pair fastest, whose sums differ from the
- * first launch's in their last bits (bit-identical only with PHOVO_GN_TAIL_SAME_PLAN=1, a test switch). */
+ * within the parity bar; on levels of >= 16384 pixels the later launches use the geometry that runs ONE pair fastest,
+ * whose sums differ from the first launch's in their last bits (bit-identical only with PHOVO_GN_TAIL_SAME_PLAN=1, a
+ * test switch).  The later launches, and everything the pairs they hold still have to do on the following levels, run
+ * on a second stream of the engine beside the first launches of those levels (same results: PHOVO_GN_OVERLAP=0 puts
+ * everything on one stream). */
 int phovo_engine_set_iteration_cap(phovo_engine *e, int cap);
 /* 1: a pair's result does not depend on how many other pairs are aligned with it -- every batch, whatever its size,
  * takes the SAME kernels with the same geometries (no latency geometry for <= 8 pairs, no automatic wide form for
