@@ -104,7 +104,7 @@ struct phovo_engine {
   int tail_stages = 3;                         // launches of a capped level: 3 = caps at iter_cap and 3 x iter_cap (PHOVO_GN_TAIL_STAGES=2: one cap)
   bool tail_same_plan = false;                 // PHOVO_GN_TAIL_SAME_PLAN=1: second launch with the first one's geometry (A/B, tests)
   bool overlap_levels = true;                  // PHOVO_GN_OVERLAP=0: every launch of an enqueue on ONE stream (A/B, tests)
-  int *d_marks = nullptr;                      // [PHOVO_MAX_LEVELS][pairs] "handed over by the level's first launch" (view into d_pairs)
+  int *d_marks = nullptr;                      // [pairs] 1 = on the side list of the long pairs' chain (view into d_pairs)
   int tail_mid_plan = 2;                       // PHOVO_GN_TAIL_MID_PLAN, bit 0: the middle launch of a three-launch level takes the first launch's
                                                // geometry instead of the latency geometry; bit 1 (default): so does the second launch of a
                                                // two-launch level -- small workgroups find places beside the next level's first launch, a
@@ -205,9 +205,9 @@ PairLayout pair_layout(int n_pairs)
   l.handover = l.heads + sizeof(int) * HEAD_SETS * PHOVO_MAX_LEVELS * QUEUE_HEADS_INTS;
   l.handover_stride = n2 + 2;                   // ints per level: the list of handed-over pairs and, at [n_pairs], its length
   l.marks = l.handover + sizeof(int) * l.handover_stride * 2 * PHOVO_MAX_LEVELS;       // two lists per level
-  l.marks_stride = n2;                          // ints per level: 1 = handed over by the level's first launch
+  l.marks_stride = n2;                          // ints: 1 = on the side list (handed over by a capped first launch), one array per enqueue
   // the cumulative side list of the long pairs' chain (enqueue): [n2 + 2] like a hand-over list, then one count snapshot per level
-  l.side = l.marks + sizeof(int) * l.marks_stride * PHOVO_MAX_LEVELS;
+  l.side = l.marks + sizeof(int) * l.marks_stride;
   l.total = l.side + sizeof(int) * (l.handover_stride + PHOVO_MAX_LEVELS);
   return l;
 }

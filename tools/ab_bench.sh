@@ -1,11 +1,11 @@
 #!/bin/bash
 # A/B of two builds of libphovo_hip.so on the GPU box (through gpurun, from the repository root):
-#     bash tools/ab_bench.sh gpurun_out/r3/ab1 [library B, default photoconsistency-visual-odometry_amd/libphovo_hip_r2.so]
+#     bash tools/ab_bench.sh gpurun_out/r3/ab1 <library B>      (e.g. a build of an earlier commit, or one with -DPHOVO_AB_*)
 # Runs bench.py (no CPU legs) in its three diagnostic shapes -- shipped thresholds, fixed iterations, every plane streamed
 # once -- with the in-tree library and with library B, and prints one line per run.
 set -o pipefail
 OUT=$1
-B=${2:-photoconsistency-visual-odometry_amd/libphovo_hip_r2.so}
+B=${2:?library B (a second build of libphovo_hip.so) is required}
 mkdir -p "$OUT"
 run() {   # name, library ("" = in-tree), bench arguments
   local name=$1 lib=$2; shift 2
