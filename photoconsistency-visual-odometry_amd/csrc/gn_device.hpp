@@ -40,9 +40,9 @@ __device__ __forceinline__ double uniform_f64(double v)
 // workgroup -- a pair's prologue (state, sincos, pose constants), wave 0's solve / update / pose constants of every
 // iteration, the write-back and the draw of the next pair -- are a few hundred DEPENDENT fp64 instructions of ONE wave
 // while the other waves of its workgroup stand at a barrier; with four waves per SIMD that wave gets about every fourth
-// issue slot (the pose constants take 1.2 us for a pair alone on its CU and 5.4 us on a full chip: 5.4 of the 9 us
-// between two pairs of a workgroup, tools/queue_timeline.py).  Raising its priority (s_setprio 3) was measured in round 3
-// and is NOT kept: shipped thresholds 1.649 -> 1.617 M alignments/s (-2 %), every plane streamed once +1 %, fixed
+// issue slot.  Raising its priority (s_setprio 3) was measured in round 3 -- at a time when the pose constants still took
+// 5.4 of the 9 us between two pairs of a workgroup (tools/queue_timeline.py; the cause was elsewhere, see
+// write_pose_constants) -- and is NOT kept: shipped thresholds 1.649 -> 1.617 M alignments/s (-2 %), every plane streamed once +1 %, fixed
 // iterations -0.2 %: the chip is bound by vector issue, so the slots the serial wave wins are slots the streaming waves
 // of the other workgroups lose -- the gap between a workgroup's pairs is not idle time of the CU.  (s_setprio is a scalar
 // instruction and ignores EXEC: wave-uniform control only.)
