@@ -319,9 +319,10 @@ def test_rank_deficient_normal_equations_are_flagged_or_agree(n_valid):
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("yml", ["config_4_level_optimization_analytic.yml", "config_5_level_optimization_analytic.yml"])
 def test_overlapping_levels_change_nothing_but_the_clock(yml, monkeypatch):
-    """With the shipped thresholds the follow-up launches of a capped level (the few long pairs) run on a second stream
-    while the next level's first launch takes every pair that is not waiting for them, and a second first launch takes
-    the rest afterwards (engine.cpp, enqueue).  Same kernels and geometries per pair either way: 1200 pairs (12 problems,
+    """With the shipped thresholds the pairs a capped first launch hands over (the few long ones) belong to a second
+    stream from then on -- their follow-up launches and their share of every later level (a side launch per level that takes
+    the cumulative side list) -- while the first launches of the later levels pass them by on the engine's stream
+    (engine.cpp, enqueue: the long pairs' chain).  Same kernels and geometries per pair either way: 1200 pairs (12 problems,
     plane and layered, short and long ones, x 100) must come out BIT-identical with PHOVO_GN_OVERLAP=0 (everything on
     one stream) -- states, iteration counts, valid pixels, gradient norms -- and equal to the oracle's."""
     ncfg = native.read_config_file(os.path.join(CFG_DIR, yml))
