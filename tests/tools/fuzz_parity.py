@@ -26,15 +26,18 @@ rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 with_ext = "ext" in sys.argv[3:]
 big = "big" in sys.argv[3:]
 bad, worst, variants, fallbacks = 0, 0.0, {}, 0
+# FUZZ_ONLY=12,345: replay the random draws of every case but run only these (to look at a failure again)
+only = {int(c) for c in os.environ["FUZZ_ONLY"].split(",")} if os.environ.get("FUZZ_ONLY") else None
 for case in range(cases):
+    active = only is None or case in only
     nl = int(rs.randint(1, 3 if big else 4))
     unit = 2 ** (nl - 1)
     w = int(rs.randint(240, 700) if big else rs.randint(16, 330)) // unit * unit + (unit if rs.rand() < 0.5 else 0)
     h = int(rs.randint(200, 500) if big else rs.randint(12, 250)) // unit * unit + (unit if rs.rand() < 0.5 else 0)
     w, h = max(w, 8 * unit), max(h, 8 * unit)
-    p = synthetic.make_pair(1000 + case, w, h, holes=float(rs.choice([0.0, 0.02, 0.2])),
-                            trans=float(rs.choice([0.002, 0.02, 0.08])),
-                            rot=float(rs.choice([0.001, 0.01, 0.05, 0.25] if big else [0.001, 0.01, 0.05])))
+    kw = dict(holes=float(rs.choice([0.0, 0.02, 0.2])), trans=float(rs.choice([0.002, 0.02, 0.08])),
+              rot=float(rs.choice([0.001, 0.01, 0.05, 0.25] if big else [0.001, 0.01, 0.05])))
+    p = synthetic.make_pair(1000 + case, w, h, **kw) if active else dict(K=synthetic.intrinsics(w, h), depth0=np.zeros((h, w)))
     K = p["K"].copy()
     if rs.rand() < 0.6:                     # principal point / focal lengths that are not exactly representable
         K[0, 2] += rs.uniform(-3, 3)
@@ -56,6 +59,15 @@ for case in range(cases):
     ocfg = oracle.make_config(num_levels=nl, max_iter=max_iter, min_grad=min_grad, lam=lam)
     init = None if rs.rand() < 0.5 else rs.uniform(-1, 1, 6) * np.array([0.02, 0.02, 0.02, 0.01, 0.01, 0.01])
     storage, huber, bilinear, corrected = native.STORAGE_F64, None, False, False
+    if not active:                          # the remaining draws of this case, in order, and on to the next one
+        if with_ext:
+            rs.randint(0, 3)
+            if not rs.rand() < 0.4:
+                [rs.choice([0.0, 0.02, 0.1]) for _ in range(nl)]
+            if rs.rand() < 0.5:
+                rs.rand()
+        rs.choice([40, 300] if big else [1, 3, 40])
+        continue
     if with_ext:
         storage = [native.STORAGE_F64, native.STORAGE_F32, native.STORAGE_F16][int(rs.randint(0, 3))]
         huber = None if rs.rand() < 0.4 else [float(rs.choice([0.0, 0.02, 0.1])) for _ in range(nl)]
