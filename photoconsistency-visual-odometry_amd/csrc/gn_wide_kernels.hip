@@ -182,6 +182,7 @@ __global__ __launch_bounds__(WT) void k_wide_pass1(const GNLevelArgs A, double *
   int *g_owner = A.g_owner + (size_t)pair * (size_t)n;
   const double fx = A.fx, fy = A.fy, ox = A.ox, oy = A.oy, ifx = A.ifx, ify = A.ify;
   const double min_d = A.min_depth, max_d = A.max_depth, dW = (double)W, dH = (double)H;
+  const RowColFromIndex rc_map = make_rowcol_from_index(W);
   // The four depths of this wave are requested before anything else: a wave's memory counter retires in order, so a
   // load issued behind one of the global atomics below would wait for that atomic.
   constexpr int CPW = TILE_CHUNKS / WNW;      // chunks per wave
@@ -197,9 +198,10 @@ __global__ __launch_bounds__(WT) void k_wide_pass1(const GNLevelArgs A, double *
     bool inb = false;
     const double pz = pzs[j];                                             // :279
     if (k < n && min_d < pz && pz < max_d) {                              // :280
-      const int r = k / W, c = k - r * W;
-      const double px = ((double)c - ox) * pz * ifx;                      // :282
-      const double py = ((double)r - oy) * pz * ify;                      // :283
+      double cd, rd;                                                      // (row, column) without an integer division
+      rowcol_from_index((double)k, rc_map, cd, rd);
+      const double px = (cd - ox) * pz * ifx;                             // :282
+      const double py = (rd - oy) * pz * ify;                             // :283
       const double X = ((P.t15 * px + P.r01 * py) + P.r02 * pz) + P.cx;   // :291
       const double Y = ((P.t14 * px + P.r11 * py) + P.r12 * pz) + P.cyy;
       const double Z = ((-P.t3 * px + P.t1 * py) + P.t2 * pz) + P.cz;
@@ -241,6 +243,7 @@ __global__ __launch_bounds__(WT) void k_wide_pass2(const GNLevelArgs A, const do
   double acc[NRED];
 #pragma unroll
   for (int j = 0; j < NRED; j++) acc[j] = 0.0;
+  const RowColFromIndex rc_map = make_rowcol_from_index(W);
   int n_rows = 0;                   // Jacobian rows this wave fills (popcount of its chunks' ballots)
   // Every load of the wave's four chunks goes out first -- owners, then the planes, then the gathers that need the
   // owners -- and the owner slots are reset only after the last load has been issued: issued in between, each store and
@@ -283,9 +286,10 @@ __global__ __launch_bounds__(WT) void k_wide_pass2(const GNLevelArgs A, const do
     const double pz = pzs[j];
     const double gxi = gxs[j], gyi = gys[j];
     const double res = o >= 0 ? i1s[j] - i0s[j] : 0.0;                    // :308-309,358
-    const int r = k / W, c = k - r * W;
-    const double px = ((double)c - ox) * pz * ifx;
-    const double py = ((double)r - oy) * pz * ify;
+    double cd, rd;
+    rowcol_from_index((double)k, rc_map, cd, rd);
+    const double px = (cd - ox) * pz * ifx;
+    const double py = (rd - oy) * pz * ify;
     // same factored Jacobian as gn_level_kernel (see the derivation there)
     const double Zr = py * P.t1 + pz * P.t2 - px * P.t3;
     const double t25 = fast_rcp(P.cz + Zr);                               // :313
