@@ -1,7 +1,8 @@
 """Soak test of the work queue's pair hand-over: N launches of 2500 shuffled copies of three problems (5-level
 configuration, 5 fixed iterations per active level); every copy of a problem must come out bit-identical in every launch.
-    python tools/queue_soak.py [launches=500] [fixed|shipped|slide]
-`shipped` keeps the yml's thresholds instead (data-dependent termination: the capped two- / three-launch levels and their
+    python tools/queue_soak.py [launches=500] [fixed|shipped|layered|slide]
+`layered` is `shipped` on problems of the layered scene (most pairs are handed over: the long pairs' chain carries the
+batch); `shipped` keeps the yml's thresholds instead (data-dependent termination: the capped two- / three-launch levels and their
 hand-over lists); `slide` soaks the sliding-window kernel (320x240, one level, 6 fixed iterations, a problem with a 0.3 rad
 in-plane rotation among them, i.e. its hand-over to the exact kernel too).
 Before the explicit LDS wait in front of the loop-head barrier about one launch in ten failed."""
@@ -28,6 +29,10 @@ elif mode == "slide":
 probs = [synthetic.make_pair(21, W, H, holes=0.02, trans=0.004, rot=0.002),
          synthetic.make_pair(22, W, H, holes=0.0, trans=0.03, rot=0.015),
          synthetic.make_pair(23, W, H, holes=0.05, trans=0.06, rot=0.03)]
+if mode == "layered":               # shipped thresholds on the layered scene: two of three problems run long on every level,
+    probs = [synthetic.make_pair(31, W, H, scene="layered", trans=0.05, rot=0.012, invalid=0.25),        # so most pairs are
+             synthetic.make_pair(22, W, H, holes=0.0, trans=0.03, rot=0.015),                            # handed over and the
+             synthetic.make_pair(33, W, H, scene="layered", trans=0.08, rot=0.02, invalid=0.3)]          # side list is long
 if mode == "slide":                 # one problem that leaves the window: rendered with a large in-plane rotation
     from phovo_amd import se3
     scene = synthetic.Scene(91)
