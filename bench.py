@@ -85,59 +85,6 @@ def algorithmic_bytes(level_sizes, iterations):
     return sum(5.0 * 8.0 * n * it for n, it in zip(level_sizes, iterations))
 
 
-def capped_launch_work(it, level_sizes, max_iter, min_grad, plane_bytes, iter_cap=4, tail_stages=3):
-    """Pair-iterations and algorithmic bytes of EVERY launch of one enqueue with data-dependent termination, from the
-    iteration counts the pairs reported -- the schedule of csrc/engine.cpp (phovo_engine_enqueue_align), restated: a level
-    with a gradient threshold and max_num_iterations above the cap is a first launch capped at `iter_cap` iterations, then
-    (levels of >= 16384 pixels with max_num_iterations > 3 x cap) one capped at 3 x cap and a last one, or (smaller levels)
-    one last launch.  A pair a capped first launch hands over is MARKED and from then on belongs to the second stream
-    (the long pairs' chain): the first launch of every later level leaves the marked pairs out and a side launch takes
-    exactly those.  Levels whose owner map does not fit LDS (more than 38 828 pixels) end the chain: sliding-window
-    kernel + exact kernel, all pairs.  Order = the order the host enqueues the launches in (what a rocprofv3 trace lists
-    by Dispatch_Id).  The reference has none of this: one Optimize() loop per pair (...Analytic.h:500-563)."""
-    iter_cap = int(os.environ.get("PHOVO_GN_ITER_CAP", iter_cap))
-    tail_stages = int(os.environ.get("PHOVO_GN_TAIL_STAGES", tail_stages))
-    overlap = os.environ.get("PHOVO_GN_OVERLAP", "1") != "0"
-    out = []
-    marked = np.zeros(len(it), dtype=bool)          # on the side list: handed over by a capped first launch of an earlier level
-    chain_on = False                                # the second stream runs the marked pairs (the launches exist even if none is)
-    levels = [l for l in range(len(max_iter) - 1, -1, -1) if max_iter[l] > 0]
-
-    def chainable(l):
-        return level_sizes[l] <= 38828
-    for li, l in enumerate(levels):
-        n_it = it[:, l].astype(np.int64)
-
-        def add(name, pair_iterations, pairs):
-            out.append(dict(level=l, launch=name, pairs=int(pairs), pair_iterations=int(pair_iterations),
-                            algorithmic_bytes=float(plane_bytes * level_sizes[l] * pair_iterations)))
-        if not chainable(l):
-            chain_on = False
-            add("sliding-window kernel, all pairs (and whatever its exact fallback finishes)", n_it.sum(), len(n_it))
-            add("exact kernel for the pairs that left the window (their iterations are counted in the launch before)", 0, 0)
-            continue
-        capped = iter_cap > 0 and min_grad[l] > 0.0 and max_iter[l] > iter_cap
-        nxt_ok = li + 1 < len(levels) and chainable(levels[li + 1])
-        chain_next = bool(overlap and nxt_ok and (chain_on or capped))
-        first = np.minimum(n_it, iter_cap if capped else max_iter[l])
-        if chain_on:
-            add("first, pairs not on the side list", first[~marked].sum(), (~marked).sum())
-            add("side launch: the pairs handed over at an earlier level", first[marked].sum(), marked.sum())
-        else:
-            add("first", first.sum(), len(n_it))
-        if capped:
-            cap2 = 3 * iter_cap
-            if tail_stages >= 3 and max_iter[l] > cap2 and level_sizes[l] >= 16384:
-                add(f"follow-up, iterations {iter_cap + 1}..{cap2}", np.clip(n_it - iter_cap, 0, cap2 - iter_cap).sum(), (n_it > iter_cap).sum())
-                add(f"follow-up, iterations {cap2 + 1}..", np.maximum(n_it - cap2, 0).sum(), (n_it > cap2).sum())
-            else:
-                add(f"follow-up, iterations {iter_cap + 1}..", np.maximum(n_it - iter_cap, 0).sum(), (n_it > iter_cap).sum())
-            if chain_next:
-                marked = marked | (n_it > iter_cap)
-        chain_on = chain_next
-    return out
-
-
 ZERO_COPY = {"ok": None}      # None = not probed yet; decided once by probe_zero_copy() outside the timed region
 
 
@@ -328,6 +275,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         wall = float(tmax.item())
     states, reports = eng.fetch_results(n_local, want_reports=True)
+    timed_launches = eng.last_launches()         # what one timed step launched, as the engine recorded it
     iters = np.array([list(r.iterations[:nl]) for r in reports])
     nonfinite = int(sum(1 for r in reports if r.flags & native.PAIR_NONFINITE))
     window_fallback = int(sum(1 for r in reports if r.flags & native.PAIR_WINDOW_FALLBACK))
@@ -416,11 +364,10 @@ def main():
                         max_iterations_per_level=[int(x) for x in it2.max(axis=0)],
                         avg_launch_ms_per_level=[float(x) / k2 for x in lv2[:nl]],
                         avg_enqueue_ms=float(lv2[native.MAX_LEVELS]) / k2,
-                        note="per-level spans may overlap: the follow-up launches of a capped level run on a second stream "
-                             "beside the next level's first launch; avg_enqueue_ms is first launch to last",
+                        note="a fused launch covers several levels: its span is reported at the coarsest of them; "
+                             "avg_enqueue_ms is first launch to last",
                         iteration_histogram=hist,
-                        launches=capped_launch_work(it2, level_sizes, max_iter,
-                                                    [float(cfg_ref.min_gradient_norm[l]) for l in range(nl)], plane_bytes))
+                        launches=eng.last_launches())
 
     # ---- PCIe-inclusive figure (never `value`): raw frames in host memory -> poses --------------------------
     # batched u16-depth upload + device pyramids + Optimize() with the shipped thresholds, one sequence of
@@ -580,7 +527,7 @@ def main():
             "cpu_baseline_all_cores": cpu_all,
             "reference_termination": ref_term,
             # --thresholds shipped (diagnostic): every launch of the timed enqueue with its share of the work, host order
-            "launches": capped_launch_work(iters, level_sizes, max_iter, min_grad_timed, plane_bytes) if shipped else None,
+            "launches": timed_launches,
             "end_to_end_pcie_inclusive": e2e,
             "single_pair": single,
         }

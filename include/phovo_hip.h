@@ -223,20 +223,21 @@ int phovo_engine_set_wide_policy(phovo_engine *e, int policy);
  * by the exact kernel (owner map in HBM) for the pairs whose warp left the window.  policy: 0 = automatic (that), -1 =
  * exact kernel only.  Results are the same either way (tests/test_gpu_parity.py). */
 int phovo_engine_set_slide_policy(phovo_engine *e, int policy);
-/* With a gradient threshold (min_gradient_norm > 0) and max_num_iterations above `cap`, a level that the persistent
- * kernel takes in its throughput geometry (every batch of more than 8 pairs that does not go to the wide form; with
- * phovo_engine_set_batch_invariant every batch) runs as two or three launches: every pair for at most `cap` iterations,
- * then the pairs still running, all started together, to their end (the few long pairs otherwise finish one per CU
- * after the queue is empty).  Default 4; 0 = one launch.  Iteration counts are identical either way and poses agree
- * within the parity bar; on levels of >= 16384 pixels the later launches use the geometry that runs ONE pair fastest,
- * whose sums differ from the first launch's in their last bits (bit-identical only with PHOVO_GN_TAIL_SAME_PLAN=1, a
- * test switch).  The later launches, and everything the pairs they hold still have to do on the following levels, run
- * on a second stream of the engine beside the first launches of those levels (same results: PHOVO_GN_OVERLAP=0 puts
- * everything on one stream). */
-int phovo_engine_set_iteration_cap(phovo_engine *e, int cap);
+/* Consecutive pyramid levels in ONE launch.  The reference's Optimize() loops per pair over levels
+ * (CPhotoconsistencyOdometryAnalytic.h:502-563); with a gradient threshold (min_gradient_norm > 0, :388) a pair leaves a
+ * level after a data-dependent number of iterations, and one launch per level would make every level boundary a boundary
+ * for the whole batch.  PHOVO_FUSION_AUTO (default): where two or more consecutive active levels each fit the 512-thread
+ * scatter kernel with its owner map in half a CU's LDS (more than 2048 and up to about 19 700 pixels: 80x60 and 160x120 of
+ * a 640x480 pyramid) and at least one of them has a gradient threshold, those levels are one persistent launch in which a
+ * workgroup runs a pair through all of them back to back.  PHOVO_FUSION_OFF: one launch per level, each in the geometry
+ * that suits it alone (what a configuration without thresholds gets anyway).  PHOVO_FUSION_SPLIT: one launch per level in
+ * the geometry of the fused launch -- bit-identical to PHOVO_FUSION_AUTO, for tests.  Iteration counts are the same in all
+ * three; poses agree to the parity bar between AUTO and OFF (other summation order on the smaller levels). */
+enum { PHOVO_FUSION_AUTO = 0, PHOVO_FUSION_OFF = -1, PHOVO_FUSION_SPLIT = -2 };
+int phovo_engine_set_level_fusion(phovo_engine *e, int mode);
 /* 1: a pair's result does not depend on how many other pairs are aligned with it -- every batch, whatever its size,
  * takes the SAME kernels with the same geometries (no latency geometry for <= 8 pairs, no automatic wide form for
- * <= 32 pairs, the capped launches of phovo_engine_set_iteration_cap for every batch), so a sequence cut into shards
+ * <= 32 pairs), so a sequence cut into shards
  * of any sizes gives bit-identical poses.  What the sequence drivers set (apps/PhotoconsistencyVisualOdometry --batch,
  * sequence.py, bench.py).  0 (default): a handful of pairs takes the forms that finish soonest (same iteration counts,
  * poses within the parity bar of the batch forms, last bits may differ). */
@@ -313,7 +314,21 @@ int phovo_engine_results_device_ptr(phovo_engine *e, void **states);
  * per-level launches, and per level (0 for levels that were not launched). */
 int phovo_engine_last_align_ms(const phovo_engine *e, double *total_ms,
                                double level_ms[PHOVO_MAX_LEVELS]);
-/* Launch geometry chosen for `level`: threads per workgroup and dynamic LDS bytes. */
+/* What the last enqueue launched, in launch order: one record per kernel launch (the wide form: per level). */
+enum { PHOVO_LAUNCH_PERSISTENT = 0,       /* gn_level_kernel: one level, one workgroup per pair at a time */
+       PHOVO_LAUNCH_FUSED = 1,            /* gn_fused_kernel: levels level_first..level_last (coarse to fine) per pair */
+       PHOVO_LAUNCH_SLIDE = 2,            /* gn_level_kernel_slide: owner ring in LDS */
+       PHOVO_LAUNCH_SLIDE_FALLBACK = 3,   /* gn_level_kernel on the pairs the sliding-window launch handed over */
+       PHOVO_LAUNCH_WIDE = 4,             /* k_wide_pass1 / k_wide_pass2 per iteration, many workgroups per pair */
+       PHOVO_LAUNCH_BILINEAR = 5 };       /* gn_level_kernel_bilinear (extension) */
+typedef struct phovo_launch_record {
+  int level_first, level_last;            /* pyramid levels the launch covers (level_first >= level_last) */
+  int kind;                               /* PHOVO_LAUNCH_* */
+  int threads, lds_bytes, workgroups;     /* launch geometry (workgroups: grid size) */
+} phovo_launch_record;
+/* count receives the number of launches; up to `capacity` of them are written to out (may be NULL). */
+int phovo_engine_last_launches(const phovo_engine *e, phovo_launch_record *out, int capacity, int *count);
+/* Launch geometry chosen for `level` when it is launched alone: threads per workgroup and dynamic LDS bytes. */
 int phovo_engine_level_launch_info(const phovo_engine *e, int level, int *threads, int *lds_bytes,
                                    int *owner_in_lds, int *source_in_lds);
 

@@ -25,6 +25,10 @@ static thread_local std::string g_last_error;
 void set_last_error(const std::string &msg) { g_last_error = msg; }
 int fail(int status, const std::string &msg) { g_last_error = msg; return status; }
 
+#ifdef PHOVO_TUNING
+bool tuning_switch(const char *name) { return std::getenv(name) != nullptr; }
+#endif
+
 #define PHOVO_HIP_CHECK(expr)                                                                   \
   do {                                                                                          \
     hipError_t _e = (expr);                                                                     \
@@ -55,10 +59,7 @@ struct phovo_engine {
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr;           // batched uploads: host-to-device copies of chunk i+1 run beside the pyramid kernels of chunk i
   hipEvent_t ev_copied[2] = {}, ev_built[2] = {};     // per staging half
-  hipStream_t tail_stream = nullptr;           // the follow-up launches of a capped level, beside the next level's first launch
-  hipEvent_t ev_firsts[PHOVO_MAX_LEVELS] = {}, ev_tails[PHOVO_MAX_LEVELS] = {};   // per level: first launch(es) done / follow-ups done
   hipEvent_t ev_total_start = nullptr, ev_total_stop = nullptr;
-  hipEvent_t ev_join = nullptr;                // the second stream's work of an enqueue, for the engine's stream to wait on
   hipEvent_t ev_start[PHOVO_MAX_LEVELS] = {};
   hipEvent_t ev_stop[PHOVO_MAX_LEVELS] = {};
   bool level_launched[PHOVO_MAX_LEVELS] = {};
@@ -98,19 +99,11 @@ struct phovo_engine {
   int *d_owner = nullptr;
   size_t owner_capacity = 0;
   bool owner_tagged = false;                   // d_owner holds tagged entries of the persistent kernel, not the -1 the wide form expects
-  int *d_work_counters = nullptr;              // [4][PHOVO_MAX_LEVELS][QUEUES_PER_LEVEL x QUEUE_HEAD_STRIDE] work-queue heads of the level launches (view into d_pairs)
-  int *d_handover = nullptr;                   // [PHOVO_MAX_LEVELS][pairs + 2] hand-over lists of the two-launch levels (view into d_pairs)
+  int *d_work_counters = nullptr;              // [2][PHOVO_MAX_LEVELS][QUEUES_PER_LEVEL x QUEUE_HEAD_STRIDE] work-queue heads of the level launches (view into d_pairs)
+  int *d_handover = nullptr;                   // [PHOVO_MAX_LEVELS][pairs + 2] hand-over lists: sliding-window kernel -> exact kernel (view into d_pairs)
   int slide_policy = 0;                        // 0 automatic (where the owner map exceeds LDS), -1 never
-  int tail_stages = 3;                         // launches of a capped level: 3 = caps at iter_cap and 3 x iter_cap (PHOVO_GN_TAIL_STAGES=2: one cap)
-  bool tail_same_plan = false;                 // PHOVO_GN_TAIL_SAME_PLAN=1: second launch with the first one's geometry (A/B, tests)
-  bool overlap_levels = true;                  // PHOVO_GN_OVERLAP=0: every launch of an enqueue on ONE stream (A/B, tests)
-  int *d_marks = nullptr;                      // [pairs] 1 = on the side list of the long pairs' chain (view into d_pairs)
-  int tail_mid_plan = 2;                       // PHOVO_GN_TAIL_MID_PLAN, bit 0: the middle launch of a three-launch level takes the first launch's
-                                               // geometry instead of the latency geometry; bit 1 (default): so does the second launch of a
-                                               // two-launch level -- small workgroups find places beside the next level's first launch, a
-                                               // 1024-thread one needs a whole CU to itself and waits for it (+1..2 % with the shipped thresholds)
-  int iter_cap = 4;                            // shipped thresholds, more pairs than workgroup slots: pairs still running after this
-                                               // many iterations of a level are finished by a second launch (0 = off)
+  int fusion = PHOVO_FUSION_AUTO;              // consecutive levels in one launch (phovo_engine_set_level_fusion)
+  std::vector<phovo_launch_record> launches;   // what the last enqueue launched, in order (phovo_engine_last_launches)
   int cu_count = 256;
   void *d_wide_ws = nullptr;                   // workspace of the wide (many-workgroups-per-pair) level form
   size_t wide_ws_capacity = 0;
@@ -187,10 +180,10 @@ bool use_wide_level(const phovo_engine *e, int n_pairs, int n_pixels)
   return n_pairs * 8 <= 256 && n_pixels >= 16384;
 }
 
-constexpr int HEAD_SETS = 4;
+constexpr int HEAD_SETS = 2;
 // Byte offsets of the per-launch pair data for n pairs (see phovo_engine::d_pairs); every section starts 8-byte aligned.
 struct PairLayout {
-  size_t src, tgt, states, reports, heads, handover, handover_stride, marks, marks_stride, side, total;
+  size_t src, tgt, states, reports, heads, handover, handover_stride, total;
 };
 PairLayout pair_layout(int n_pairs)
 {
@@ -201,14 +194,10 @@ PairLayout pair_layout(int n_pairs)
   l.states = l.tgt + sizeof(int) * n2;
   l.reports = l.states + sizeof(double) * 6 * (size_t)n_pairs;
   l.heads = l.reports + sizeof(phovo_pair_report) * (size_t)n_pairs;
-  // four sets of heads per level: every launch of a level (up to four, see enqueue) drains its own queue
+  // two sets of heads per level: the sliding-window launch of a level and the exact launch behind it drain their own queues
   l.handover = l.heads + sizeof(int) * HEAD_SETS * PHOVO_MAX_LEVELS * QUEUE_HEADS_INTS;
   l.handover_stride = n2 + 2;                   // ints per level: the list of handed-over pairs and, at [n_pairs], its length
-  l.marks = l.handover + sizeof(int) * l.handover_stride * 2 * PHOVO_MAX_LEVELS;       // two lists per level
-  l.marks_stride = n2;                          // ints: 1 = on the side list (handed over by a capped first launch), one array per enqueue
-  // the cumulative side list of the long pairs' chain (enqueue): [n2 + 2] like a hand-over list, then one count snapshot per level
-  l.side = l.marks + sizeof(int) * l.marks_stride;
-  l.total = l.side + sizeof(int) * (l.handover_stride + PHOVO_MAX_LEVELS);
+  l.total = l.handover + sizeof(int) * l.handover_stride * PHOVO_MAX_LEVELS;
   return l;
 }
 
@@ -443,14 +432,8 @@ int phovo_engine_create(int device, phovo_engine **out)
   phovo_extensions_default(&e->ext);
   hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
   if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking);
-  if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->tail_stream, hipStreamNonBlocking);
   if (he == hipSuccess) he = hipEventCreate(&e->ev_total_start);
   if (he == hipSuccess) he = hipEventCreate(&e->ev_total_stop);
-  if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
-  for (int l = 0; l < PHOVO_MAX_LEVELS && he == hipSuccess; l++) {
-    he = hipEventCreateWithFlags(&e->ev_firsts[l], hipEventDisableTiming);
-    if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_tails[l], hipEventDisableTiming);
-  }
   for (int i = 0; i < 2 && he == hipSuccess; i++) {
     he = hipEventCreateWithFlags(&e->ev_copied[i], hipEventDisableTiming);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_built[i], hipEventDisableTiming);
@@ -463,12 +446,6 @@ int phovo_engine_create(int device, phovo_engine **out)
   }
   if (he == hipSuccess) he = gn_prepare_kernels();
   if (he == hipSuccess) he = gn_prepare_slide_kernels();
-  e->slide_policy = std::getenv("PHOVO_GN_NO_SLIDE") ? -1 : 0;        // A/B switches for tools/
-  e->tail_same_plan = std::getenv("PHOVO_GN_TAIL_SAME_PLAN") != nullptr;
-  if (const char *st = std::getenv("PHOVO_GN_TAIL_STAGES")) e->tail_stages = std::atoi(st);
-  if (const char *st = std::getenv("PHOVO_GN_TAIL_MID_PLAN")) e->tail_mid_plan = std::atoi(st);
-  if (const char *st = std::getenv("PHOVO_GN_OVERLAP")) e->overlap_levels = std::atoi(st) != 0;
-  if (const char *cap = std::getenv("PHOVO_GN_ITER_CAP")) e->iter_cap = std::atoi(cap) > 0 ? std::atoi(cap) : 0;
   if (he == hipSuccess) {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) e->cu_count = cus;
@@ -486,7 +463,6 @@ int phovo_engine_destroy(phovo_engine *e)
   if (!e) return PHOVO_OK;
   (void)hipSetDevice(e->device);
   if (e->copy_stream) (void)hipStreamSynchronize(e->copy_stream);
-  if (e->tail_stream) (void)hipStreamSynchronize(e->tail_stream);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   free_pool(e);
   free_pairs(e);
@@ -498,15 +474,9 @@ int phovo_engine_destroy(phovo_engine *e)
     if (e->ev_copied[i]) (void)hipEventDestroy(e->ev_copied[i]);
     if (e->ev_built[i]) (void)hipEventDestroy(e->ev_built[i]);
   }
-  for (int l = 0; l < PHOVO_MAX_LEVELS; l++) {
-    if (e->ev_firsts[l]) (void)hipEventDestroy(e->ev_firsts[l]);
-    if (e->ev_tails[l]) (void)hipEventDestroy(e->ev_tails[l]);
-  }
   if (e->ev_total_start) (void)hipEventDestroy(e->ev_total_start);
   if (e->ev_total_stop) (void)hipEventDestroy(e->ev_total_stop);
-  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
-  if (e->tail_stream) (void)hipStreamDestroy(e->tail_stream);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return PHOVO_OK;
@@ -611,11 +581,12 @@ int phovo_engine_set_slide_policy(phovo_engine *e, int policy)
   return PHOVO_OK;
 }
 
-int phovo_engine_set_iteration_cap(phovo_engine *e, int cap)
+int phovo_engine_set_level_fusion(phovo_engine *e, int mode)
 {
-  if (!e) return fail(PHOVO_E_INVALID_ARGUMENT, "set_iteration_cap: null");
-  if (cap < 0) return fail(PHOVO_E_INVALID_ARGUMENT, "set_iteration_cap: cap must be >= 0");
-  e->iter_cap = cap;
+  if (!e) return fail(PHOVO_E_INVALID_ARGUMENT, "set_level_fusion: null");
+  if (mode != PHOVO_FUSION_AUTO && mode != PHOVO_FUSION_OFF && mode != PHOVO_FUSION_SPLIT)
+    return fail(PHOVO_E_INVALID_ARGUMENT, "set_level_fusion: unknown mode");
+  e->fusion = mode;
   return PHOVO_OK;
 }
 
@@ -1008,7 +979,6 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
   e->d_reports = reinterpret_cast<phovo_pair_report *>(e->d_pairs + pl.reports);
   e->d_work_counters = reinterpret_cast<int *>(e->d_pairs + pl.heads);
   e->d_handover = reinterpret_cast<int *>(e->d_pairs + pl.handover);
-  e->d_marks = reinterpret_cast<int *>(e->d_pairs + pl.marks);
   std::memset(e->h_up, 0, pl.reports);
   std::memcpy(e->h_up + pl.src, source_frames, sizeof(int) * (size_t)n_pairs);
   std::memcpy(e->h_up + pl.tgt, target_frames, sizeof(int) * (size_t)n_pairs);
@@ -1019,52 +989,15 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
   PHOVO_HIP_CHECK(hipMemsetAsync(e->d_pairs + pl.reports, 0, pl.total - pl.reports, e->stream));
   PHOVO_HIP_CHECK(hipEventRecord(e->ev_total_start, e->stream));
 
-  // The long pairs' own chain (shipped thresholds).  A capped level ends with one or two launches that hold a few per
-  // cent of the pairs -- the long ones -- and leave most CUs idle (80x60, 8192 pairs: 0.33 of 1.1 ms), and the next
-  // level's share of those pairs is another launch of a few hundred workgroups.  Pairs are independent, so ALL of that runs
-  // on a SECOND stream, beside the first launches of the following levels on the engine's stream:
-  //   * the first launch of a capped level MARKS every pair it hands over and appends it, once, to a cumulative side list;
-  //   * from then on a marked pair belongs to the second stream: the first launch of every later level passes marked
-  //     pairs by (draw_pair_any), and a "side" first launch on the second stream takes the side list -- the prefix of it
-  //     that existed when the level before had been dealt out (a count snapshot taken on the engine's stream; newer
-  //     entries are pairs this very level hands over, and those belong to its follow-up launches);
-  //   * the follow-up launches of a level go to the second stream too, behind the side launch (stream order) and behind
-  //     the engine stream's first launch (event).
-  // The engine's stream never waits for the second one before the end of the enqueue.  Same kernels, same geometries,
-  // same arithmetic per pair and level as on one stream -- which launch runs a pair's level depends on the level's size
-  // and on the pair's own iteration counts only -- so results are bit-identical with and without
-  // (PHOVO_GN_OVERLAP=0: everything on ONE stream; tests/test_gpu_round3.py compares the two).
   const PairLayout lay = pair_layout(n_pairs);
-  int *const marks = e->d_marks;                                           // [pairs] 1 = on the side list
-  int *const side_list = reinterpret_cast<int *>(e->d_pairs + lay.side);   // [pairs] + count at [n_pairs]
-  int *const side_snap = side_list + lay.handover_stride;                  // [PHOVO_MAX_LEVELS] count snapshots, one per level
-  bool chain_on = false;          // marked pairs may exist: first launches pass them by, the second stream runs them
-  bool tail_dirty = false;        // the second stream holds work of this enqueue that the engine's stream has not waited for
-  int prev_level = -1;            // the level whose first launch (and snapshot) ev_firsts[prev_level] stands for
-  auto join_tail = [&]() -> hipError_t {
-    if (!tail_dirty) return hipSuccess;
-    tail_dirty = false;
-    hipError_t he = hipEventRecord(e->ev_join, e->tail_stream);
-    if (he != hipSuccess) return he;
-    return hipStreamWaitEvent(e->stream, e->ev_join, 0);
+  e->launches.clear();
+  auto record = [&](int first, int last, int kind, int threads, int lds, int wgs) {
+    phovo_launch_record r{};
+    r.level_first = first; r.level_last = last; r.kind = kind; r.threads = threads; r.lds_bytes = lds; r.workgroups = wgs;
+    e->launches.push_back(r);
   };
-  // does level m run the persistent kernel with its owner map in LDS (the only form that takes part)?
-  auto chainable = [&](int m) {
-    const LevelPool &nx = e->levels[m];
-    if (e->ext.sampling == PHOVO_SAMPLING_BILINEAR) return false;
-    if (use_wide_level(e, n_pairs, nx.n) && !(e->ext.huber_delta[m] > 0.0)) return false;
-    const bool few_m = !e->batch_invariant && n_pairs <= LATENCY_PAIRS && nx.plan_few_ok &&
-                       nx.plan_few.owner_in_lds == nx.plan.owner_in_lds;
-    return (few_m ? nx.plan_few : nx.plan).owner_in_lds;
-  };
-  auto next_active = [&](int l) {
-    for (int m = l - 1; m >= 0; m--)
-      if (e->cfg.max_num_iterations[m] > 0) return m;
-    return -1;
-  };
-
-  for (int l = e->cfg.num_levels - 1; l >= 0; l--) {                                 // coarse to fine  :502-503
-    if (e->cfg.max_num_iterations[l] <= 0) continue;                                 // :526 (nothing observable happens)
+  auto persistent_grid = [&](int wgs_per_cu) { const int slots = e->cu_count * wgs_per_cu; return n_pairs < slots ? n_pairs : slots; };
+  auto level_args = [&](int l) {
     const LevelPool &lv = e->levels[l];
     GNLevelArgs a{};
     a.w = lv.w; a.h = lv.h; a.n = lv.n; a.level = l;
@@ -1086,125 +1019,116 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
     a.g_owner = e->d_owner;
     a.n_pairs = n_pairs;
     a.work_counter = e->d_work_counters + l * QUEUE_HEADS_INTS;
-    // one queue per XCD once there are enough pairs to keep every XCD's share of the grid busy; PHOVO_QUEUE_SINGLE=1
-    // is a tuning aid for tools/ (A/B of the placement)
-    static const bool single_queue = std::getenv("PHOVO_QUEUE_SINGLE") != nullptr;
-    a.n_queues = (!single_queue && n_pairs >= 8 * 64) ? QUEUES_PER_LEVEL : 1;
+    // one queue per XCD once there are enough pairs to keep every XCD's share of the grid busy
+    a.n_queues = (!tuning_switch("PHOVO_QUEUE_SINGLE") && n_pairs >= 8 * 64) ? QUEUES_PER_LEVEL : 1;
+    return a;
+  };
+  // a handful of pairs leaves most CUs empty: such a batch takes the geometry with the shorter iteration
+  const bool few_batch = !e->batch_invariant && n_pairs <= LATENCY_PAIRS;
+  // Can level l be one of several levels of ONE launch (gn_fused_kernel)?  The persistent scatter kernel with its owner map
+  // in half a CU's LDS; not the latency geometry of a small batch, not the wide form.
+  auto fusable = [&](int l) {
+    const LevelPool &lv = e->levels[l];
+    if (e->fusion == PHOVO_FUSION_OFF || e->ext.sampling == PHOVO_SAMPLING_BILINEAR || few_batch) return false;
+    if (use_wide_level(e, n_pairs, lv.n) && !(e->ext.huber_delta[l] > 0.0)) return false;
+    return gn_level_fusable(lv.n);
+  };
+
+  for (int l = e->cfg.num_levels - 1; l >= 0; l--) {                                 // coarse to fine  :502-503
+    if (e->cfg.max_num_iterations[l] <= 0) continue;                                 // :526 (nothing observable happens)
+    const LevelPool &lv = e->levels[l];
+    GNLevelArgs a = level_args(l);
     PHOVO_HIP_CHECK(hipEventRecord(e->ev_start[l], e->stream));
-    if (!chainable(l)) {                     // this level takes all pairs in one form on the engine's stream: the chain ends
-      PHOVO_HIP_CHECK(join_tail());
-      chain_on = false;
+
+    // Data-dependent termination (a gradient threshold on any of them): the run of consecutive fusable levels that starts
+    // here goes out as ONE persistent launch in which every pair flows through those levels inside the workgroup that drew
+    // it.  Which levels form a run depends on the configuration and the level sizes only, never on the batch (apart from
+    // the latency forms of batches of <= 8 pairs, which batch_invariant switches off): see phovo_engine_set_batch_invariant.
+    // With thresholds of zero every pair runs max_num_iterations and a level boundary costs nothing: one launch per level,
+    // each in its own best geometry.
+    if (fusable(l)) {
+      int run[GN_MAX_FUSED_LEVELS], n_run = 0;
+      bool data_dependent = false;
+      for (int m = l; m >= 0 && n_run < GN_MAX_FUSED_LEVELS; m--) {
+        if (e->cfg.max_num_iterations[m] <= 0) continue;
+        if (!fusable(m)) break;
+        run[n_run++] = m;
+        if (e->cfg.min_gradient_norm[m] > 0.0) data_dependent = true;
+      }
+      if (n_run >= 2 && data_dependent && e->fusion == PHOVO_FUSION_AUTO) {
+        GNFusedArgs f{};
+        f.n_levels = n_run; f.n_pairs = n_pairs; f.n_queues = a.n_queues; f.work_counter = a.work_counter;
+        for (int i = 0; i < n_run; i++) {
+          f.lv[i] = level_args(run[i]);
+          if (f.lv[i].n > f.n_max) f.n_max = f.lv[i].n;
+        }
+        PHOVO_HIP_CHECK(gn_launch_fused(f, e->ext.plane_storage, e->cu_count, e->stream));
+        record(l, run[n_run - 1], PHOVO_LAUNCH_FUSED, 512, gn_fused_lds_bytes(f.n_max), persistent_grid(2));
+        PHOVO_HIP_CHECK(hipEventRecord(e->ev_stop[l], e->stream));
+        e->level_launched[l] = true;
+        l = run[n_run - 1];                        // (the loop's l-- moves on to the level below the run)
+        continue;
+      }
+      if (n_run >= 2 && data_dependent && e->fusion == PHOVO_FUSION_SPLIT) {
+        // the fused geometry, one launch per level: what a fused run is bit-identical to (tests)
+        GNLaunchPlan mid{};
+        (void)gn_plan_fused_geometry(lv.n, &mid);
+        PHOVO_HIP_CHECK(gn_launch_level(a, mid, e->ext.plane_storage, e->cu_count, e->stream));
+        record(l, l, PHOVO_LAUNCH_PERSISTENT, mid.threads, mid.lds_bytes, persistent_grid(mid.wgs_per_cu));
+        PHOVO_HIP_CHECK(hipEventRecord(e->ev_stop[l], e->stream));
+        e->level_launched[l] = true;
+        continue;
+      }
     }
+
     if (e->ext.sampling == PHOVO_SAMPLING_BILINEAR) {
       PHOVO_HIP_CHECK(gn_launch_level_bilinear(a, e->ext.plane_storage, e->ext.jacobian_corrected != 0, e->cu_count, e->stream));
+      record(l, l, PHOVO_LAUNCH_BILINEAR, 256, 0, persistent_grid(gn_bilinear_wgs_per_cu()));
     } else if (use_wide_level(e, n_pairs, lv.n) && !(e->ext.huber_delta[l] > 0.0)) {
       if (e->owner_tagged) {            // the wide form starts from -1 everywhere and leaves it so
         PHOVO_HIP_CHECK(fill_i32(e->d_owner, e->owner_capacity, -1, e->stream));
         e->owner_tagged = false;
       }
       PHOVO_HIP_CHECK(gn_run_level_wide(a, n_pairs, e->d_wide_ws, e->h_wide_done.data(), e->stream));
+      record(l, l, PHOVO_LAUNCH_WIDE, 256, 0, n_pairs * ((lv.n + 1023) / 1024));
     } else {
-      // a handful of pairs leaves most CUs empty: take the geometry with the shorter iteration (same owner-map placement)
-      const bool few = !e->batch_invariant && n_pairs <= LATENCY_PAIRS && lv.plan_few_ok &&
-                       lv.plan_few.owner_in_lds == lv.plan.owner_in_lds;
+      const bool few = few_batch && lv.plan_few_ok && lv.plan_few.owner_in_lds == lv.plan.owner_in_lds;
       const GNLaunchPlan &pl = few ? lv.plan_few : lv.plan;
       a.n_lds = pl.owner_in_lds ? 0 : pl.owner_lds_entries;
-      const size_t hstride = lay.handover_stride;
-      int *list0 = e->d_handover + (size_t)(2 * l) * hstride, *list1 = list0 + hstride;
+      int *list0 = e->d_handover + (size_t)l * lay.handover_stride;
       int *heads1 = e->d_work_counters + (PHOVO_MAX_LEVELS + l) * QUEUE_HEADS_INTS;
-      int *heads2 = e->d_work_counters + (2 * PHOVO_MAX_LEVELS + l) * QUEUE_HEADS_INTS;
-      int *heads3 = e->d_work_counters + (3 * PHOVO_MAX_LEVELS + l) * QUEUE_HEADS_INTS;
       if (!pl.owner_in_lds && e->slide_policy >= 0) {
         // Owner map too large for LDS: the sliding-window kernel first (owner ring in LDS); pairs whose warp leaves its
         // window are put on the hand-over list and continued, from the iteration they had reached, by the exact kernel
         // right behind it, which draws from that list.
         a.handover_out = list0;
         PHOVO_HIP_CHECK(gn_launch_level_slide(a, e->ext.plane_storage, e->cu_count, e->stream));
+        record(l, l, PHOVO_LAUNCH_SLIDE, 512, (int)gn_slide_lds_bytes(), persistent_grid(1));
         a.handover_out = nullptr; a.handover_in = list0; a.takeover_flag = PHOVO_PAIR_WINDOW_FALLBACK;
         a.work_counter = heads1; a.n_queues = 1;
         PHOVO_HIP_CHECK(gn_launch_level(a, pl, e->ext.plane_storage, e->cu_count, e->stream));
+        record(l, l, PHOVO_LAUNCH_SLIDE_FALLBACK, pl.threads, pl.lds_bytes, persistent_grid(pl.wgs_per_cu));
         e->owner_tagged = true;                              // tagged entries stay behind (the kernel wipes per pair)
-      } else if (!pl.owner_in_lds) {
-        PHOVO_HIP_CHECK(gn_launch_level(a, pl, e->ext.plane_storage, e->cu_count, e->stream));
-        e->owner_tagged = true;
       } else {
-        // Data-dependent termination: most pairs stop after a few iterations, a few run to max_num_iterations, and
-        // whichever of those a workgroup draws late finishes alone on its CU long after the queue is empty (the launch
-        // then ends with one pair per CU at that CU's own fp64 rate).  So the first launch of such a level CAPS every pair
-        // at iter_cap iterations and hands the unfinished ones over; a follow-up launch starts all of them at once, each
-        // from its stored state and iteration count, in the geometry that runs one pair fastest, and (where
-        // max_num_iterations allows) caps them again at 3 x iter_cap for a third launch -- pairs of one launch then need
-        // about the same number of iterations and finish together.  Every batch the persistent kernel takes in its
-        // throughput geometry goes this way; with batch_invariant that is EVERY batch, so that a pair's result does not
-        // depend on how many other pairs were aligned with it (a sequence gives the same trajectory file, byte for byte,
-        // however it is cut into shards: tests/test_sequence_sharded.py).
-        const bool capped = e->iter_cap > 0 && a.min_grad_norm > 0.0 && a.max_iter > e->iter_cap && !few;
-        const int nxt = next_active(l);
-        // does the long pairs' chain start here or go on below this level?
-        const bool chain_next = e->overlap_levels && nxt >= 0 && chainable(nxt) && (chain_on || capped);
-        GNLevelArgs f = a;                                   // the first launch(es) of the level
-        if (capped) { f.handover_out = list0; f.iter_cap = e->iter_cap; }
-        if (capped && chain_next) { f.mark_out = marks; f.side_out = side_list; }
-        GNLevelArgs fs = f;                                  // ... its side launch: the marked pairs, on the second stream
-        if (chain_on) f.skip_marks = marks;
-        PHOVO_HIP_CHECK(gn_launch_level(f, pl, e->ext.plane_storage, e->cu_count, e->stream));
-        if (chain_next)                                      // what is on the side list NOW is what the next level's side launch takes
-          PHOVO_HIP_CHECK(hipMemcpyAsync(side_snap + nxt, side_list + n_pairs, sizeof(int), hipMemcpyDeviceToDevice, e->stream));
-        if (chain_on) {
-          // (behind the launches of the level before that these pairs wait for: stream order; and behind the snapshot)
-          PHOVO_HIP_CHECK(hipStreamWaitEvent(e->tail_stream, e->ev_firsts[prev_level], 0));
-          fs.handover_in = side_list; fs.handover_count = side_snap + l; fs.takeover_flag = 0;
-          fs.work_counter = heads3; fs.n_queues = 1;
-          PHOVO_HIP_CHECK(gn_launch_level(fs, pl, e->ext.plane_storage, e->cu_count, e->tail_stream));
-          tail_dirty = true;
-        }
-        hipStream_t ts = e->stream;                          // where this level's follow-ups go
-        if (chain_next) {
-          PHOVO_HIP_CHECK(hipEventRecord(e->ev_firsts[l], e->stream));
-          prev_level = l;
-          ts = e->tail_stream;
-        } else {
-          PHOVO_HIP_CHECK(join_tail());                      // the chain ends with this level: its side launch first
-        }
-        if (capped) {
-          if (ts == e->tail_stream) {
-            PHOVO_HIP_CHECK(hipStreamWaitEvent(ts, e->ev_firsts[l], 0));
-            tail_dirty = true;
-          }
-          const GNLaunchPlan &tail = (!e->tail_same_plan && lv.plan_tail_ok && lv.plan_tail.owner_in_lds) ? lv.plan_tail : pl;
-          // (which geometry a launch takes depends on the level only, never on the batch size: see batch_invariant;
-          // PHOVO_GN_TAIL_MID_PLAN: A/B of the first launch's geometry for the follow-ups, +-0.5 % either way)
-          const GNLaunchPlan &mid = (e->tail_mid_plan & 1) ? pl : tail;
-          GNLevelArgs u = a;
-          u.takeover_flag = 0; u.n_queues = 1;
-          const int cap2 = 3 * e->iter_cap;
-          // (a third launch pays on the larger levels: 160x120, 8192 pairs 3.85 -> 3.63 ms; on 80x60 its fixed cost is
-          // larger than what the better balance returns)
-          if (e->tail_stages >= 3 && a.max_iter > cap2 && lv.n >= 16384) {
-            u.handover_in = list0; u.handover_out = list1; u.iter_cap = cap2; u.work_counter = heads1;
-            PHOVO_HIP_CHECK(gn_launch_level(u, mid, e->ext.plane_storage, e->cu_count, ts));
-            u.handover_in = list1; u.work_counter = heads2;
-            u.handover_out = nullptr; u.iter_cap = 0;
-            PHOVO_HIP_CHECK(gn_launch_level(u, tail, e->ext.plane_storage, e->cu_count, ts));
-          } else {
-            // two launches: the second one is "the launch right behind the first" and the last at once
-            u.handover_in = list0; u.work_counter = heads1;
-            u.handover_out = nullptr; u.iter_cap = 0;
-            PHOVO_HIP_CHECK(gn_launch_level(u, (e->tail_mid_plan & 2) ? pl : tail, e->ext.plane_storage, e->cu_count, ts));
-          }
-        }
-        chain_on = chain_next;
-        PHOVO_HIP_CHECK(hipEventRecord(e->ev_stop[l], ts));       // (the level's span ends with its last launch, on whichever stream)
-        e->level_launched[l] = true;
-        continue;
+        PHOVO_HIP_CHECK(gn_launch_level(a, pl, e->ext.plane_storage, e->cu_count, e->stream));
+        record(l, l, PHOVO_LAUNCH_PERSISTENT, pl.threads, pl.lds_bytes, persistent_grid(pl.wgs_per_cu));
+        if (!pl.owner_in_lds) e->owner_tagged = true;
       }
     }
     PHOVO_HIP_CHECK(hipEventRecord(e->ev_stop[l], e->stream));
     e->level_launched[l] = true;
   }
-  PHOVO_HIP_CHECK(join_tail());
   PHOVO_HIP_CHECK(hipEventRecord(e->ev_total_stop, e->stream));
   e->have_timing = true;
+  return PHOVO_OK;
+}
+
+int phovo_engine_last_launches(const phovo_engine *e, phovo_launch_record *out, int capacity, int *count)
+{
+  if (!e || !count) return fail(PHOVO_E_INVALID_ARGUMENT, "last_launches: null");
+  *count = (int)e->launches.size();
+  if (out)
+    for (int i = 0; i < capacity && i < *count; i++) out[i] = e->launches[(size_t)i];
   return PHOVO_OK;
 }
 
@@ -1260,7 +1184,6 @@ int phovo_engine_last_align_ms(const phovo_engine *e, double *total_ms, double l
   if (!e->have_timing) return fail(PHOVO_E_NOT_READY, "last_align_ms: nothing has been enqueued");
   PHOVO_HIP_CHECK(hipSetDevice(e->device));
   PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
-  if (e->tail_stream) PHOVO_HIP_CHECK(hipStreamSynchronize(e->tail_stream));
   for (int l = 0; l < PHOVO_MAX_LEVELS; l++) {
     double ms = 0;
     if (e->level_launched[l]) {

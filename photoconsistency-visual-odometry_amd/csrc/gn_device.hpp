@@ -36,25 +36,6 @@ __device__ __forceinline__ double uniform_f64(double v)
   return __hiloint2double(hi, lo);
 }
 
-// A/B switch, OFF in the shipped build (-DPHOVO_AB_SERIAL_PRIO turns it on; tools/ only).  The serial sections of a
-// workgroup -- a pair's prologue (state, sincos, pose constants), wave 0's solve / update / pose constants of every
-// iteration, the write-back and the draw of the next pair -- are a few hundred DEPENDENT fp64 instructions of ONE wave
-// while the other waves of its workgroup stand at a barrier; with four waves per SIMD that wave gets about every fourth
-// issue slot.  Raising its priority (s_setprio 3) was measured in round 3 -- at a time when the pose constants still took
-// 5.4 of the 9 us between two pairs of a workgroup (tools/queue_timeline.py; the cause was elsewhere, see
-// write_pose_constants) -- and is NOT kept: shipped thresholds 1.649 -> 1.617 M alignments/s (-2 %), every plane streamed once +1 %, fixed
-// iterations -0.2 %: the chip is bound by vector issue, so the slots the serial wave wins are slots the streaming waves
-// of the other workgroups lose -- the gap between a workgroup's pairs is not idle time of the CU.  (s_setprio is a scalar
-// instruction and ignores EXEC: wave-uniform control only.)
-__device__ __forceinline__ void serial_priority(bool on)
-{
-#ifdef PHOVO_AB_SERIAL_PRIO
-  if (on) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
-#else
-  (void)on;
-#endif
-}
-
 // Pose constants from the state: Rt (:219-241) and temp1..temp24 (:243-266), written with the
 // reference's association.  temp7 = -temp6, temp9 = -temp8, temp21 = -temp5, temp22 = temp2,
 // temp23 = temp1 hold exactly in IEEE arithmetic and are not stored; Rt(0,0) = temp15,
@@ -75,11 +56,7 @@ __device__ __forceinline__ void write_pose_constants(double x, double y, double 
   // compiler hoists to the top of the kernel, cannot keep under the 128-register cap and SPILLS -- nine dependent
   // scratch reloads, each a full trip to memory behind an s_waitcnt vmcnt(0), in the middle of wave 0's serial section
   // (and nine more in every pair's prologue).  Here the coefficients are scalar operands (opaque to the hoisting).
-#ifdef PHOVO_AB_LIB_SINCOS        // A/B diagnostic build only (tools/): always the library
-  const bool small_angles = false;
-#else
   const bool small_angles = __builtin_amdgcn_ballot_w64(!(fabs(ang) <= 0.78539816339744828)) == 0;
-#endif
   if (small_angles) {
     auto k = [](double v) { asm volatile("" : "+s"(v)); return v; };       // a coefficient as an SGPR pair
     const double z = ang * ang;
@@ -282,9 +259,6 @@ __device__ __forceinline__ void plane_load2<__half>(__amdgpu_buffer_rsrc_t r, in
 // that follow (tests/test_gpu_parity.py holds the poses to 1e-9 against the oracle's exact divisions).
 __device__ __forceinline__ double fast_rcp(double x)
 {
-#ifdef PHOVO_AB_IEEE_DIV          // A/B diagnostic build only (divergence class): the correctly rounded quotient
-  return 1.0 / x;
-#endif
   double r = __builtin_amdgcn_rcp(x);
   double e = fma(-x, r, 1.0);
   r = fma(r, e, r);
@@ -348,21 +322,13 @@ __device__ __forceinline__ int draw_pair(int *heads, int n_queues, int n_pairs)
   return n_pairs;
 }
 
-// Next pair for the calling workgroup: with GNLevelArgs::handover_in an index into the list an earlier launch of the level
-// left behind (length at [n_pairs], final since that launch has ended) and the pair stored there; otherwise the plain
-// queue.  n_pairs = nothing left.
+// Next pair for the calling workgroup: with GNLevelArgs::handover_in an index into the list the sliding-window launch of
+// the level left behind (length at [n_pairs], final since that launch has ended) and the pair stored there; otherwise the
+// plain queue.  n_pairs = nothing left.
 __device__ __forceinline__ int draw_pair_any(const GNLevelArgs &A)
 {
-  if (!A.handover_in) {
-    int p = draw_pair(A.work_counter, A.n_queues, A.n_pairs);
-    if (A.skip_marks) {              // (the queue heads only grow: the loop ends with a pair of this launch's or with n_pairs)
-      while (p < A.n_pairs && __hip_atomic_load(&A.skip_marks[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
-        p = draw_pair(A.work_counter, A.n_queues, A.n_pairs);
-    }
-    return p;
-  }
-  const int count = __hip_atomic_load(A.handover_count ? A.handover_count : &A.handover_in[A.n_pairs], __ATOMIC_RELAXED,
-                                      __HIP_MEMORY_SCOPE_AGENT);
+  if (!A.handover_in) return draw_pair(A.work_counter, A.n_queues, A.n_pairs);
+  const int count = __hip_atomic_load(&A.handover_in[A.n_pairs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int i = atomicAdd(A.work_counter, 1);
   return i < count ? __hip_atomic_load(&A.handover_in[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : A.n_pairs;
 }
@@ -373,10 +339,6 @@ __device__ __forceinline__ void handover_append(const GNLevelArgs &A, int pair)
 {
   const int slot = atomicAdd(&A.handover_out[A.n_pairs], 1);
   A.handover_out[slot] = pair;
-  if (A.mark_out && atomicExch(&A.mark_out[pair], 1) == 0 && A.side_out) {       // marked for the first time: onto the side list
-    const int s = atomicAdd(&A.side_out[A.n_pairs], 1);
-    A.side_out[s] = pair;
-  }
 }
 
 // v_writelane_b32: lane `lane` (wave-uniform) of `old` becomes `value` (wave-uniform); the other lanes keep theirs.
@@ -462,7 +424,6 @@ __device__ __forceinline__ void reduce_solve_update(double (&acc)[NRED], int lan
   }
   __syncthreads();
   if (wave == 0) {
-    serial_priority(true);
     double v = 0.0;
     {
       const int j = lane & (NRED - 1);
@@ -503,7 +464,6 @@ __device__ __forceinline__ void reduce_solve_update(double (&acc)[NRED], int lan
       if (last_valid < 6) s_ctl[CTL_FLAGS] |= (int)PHOVO_PAIR_RANK_DEFICIENT;
     }
     last_gnorm = gnorm;
-    serial_priority(false);
   }
   __syncthreads();
 }

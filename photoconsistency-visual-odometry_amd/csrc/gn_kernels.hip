@@ -27,6 +27,11 @@
 // The reference's `temp11 = cos(pitch)*cos(yaw)+x` transcription bug (:253) is reproduced on purpose:
 // parity with the reference's poses requires it ("read this first" item 4).
 
+//
+// Two kernels share the per-(pair, level) body below (level_body): gn_level_kernel runs ONE level for every pair it draws
+// (one launch per active level), gn_fused_kernel runs a pair through SEVERAL consecutive levels back to back inside the
+// workgroup that drew it -- the reference's own loop structure, per pair over levels (:500-563) -- so that with
+// data-dependent termination a level boundary is not a chip-wide launch boundary.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 
@@ -40,63 +45,40 @@ namespace phovo_hip {
 
 namespace {
 
-// T threads per workgroup, WPS = waves per SIMD the register allocator must leave room for
-// (2 workgroups of 512 threads per CU <=> 4).  SRC_LDS: source intensity plane staged in LDS.
-// OWNER_LDS: owner map in LDS (else in global memory).  MASK_REG: the per-pixel "warped in bounds"
-// flags of a lane live in one 64-bit register (needs <= 64 chunks per wave), else in an LDS ballot array.
-// TI / TD: storage type of the intensity+gradient planes / of the depth plane (double = reference-exact).
-template <int T, int WPS, bool SRC_LDS, bool OWNER_LDS, bool MASK_REG, typename TI, typename TD>
-__global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
+// LDS blocks of a workgroup (offsets are multiples of 8; s_owner is sized for the largest level the workgroup will run).
+struct LevelLds {
+  double *cst;                 // [32]  pose constants of the running iteration
+  double *state;               // [8]   state vector
+  double *red;                 // [NW][NRED] one row of wave sums per wave
+  int *ctl;                    // [CTL_COUNT]
+  unsigned long long *mask;    // [n_chunks] in-bounds ballots (!MASK_REG)
+  int *owner;                  // owner map (OWNER_LDS) or its leading n_lds entries (owner map in HBM)
+  double *i0;                  // [n] source intensity (SRC_LDS)
+};
+
+// One frame pair at one pyramid level: every Gauss-Newton iteration of that level, from iteration `iteration` (0, or the
+// count an earlier launch had reached) until the termination test stops it (:547-549).  Called by ALL threads of the
+// workgroup with workgroup-uniform arguments; the state comes from A.states (HBM) or, with state_in_lds, from L.state,
+// where the level before left it; on return L.state holds the result and `iteration` the iterations executed in all.
+// T threads per workgroup.  SRC_LDS: source intensity plane staged in LDS.  OWNER_LDS: owner map in LDS (else in global
+// memory).  MASK_REG: the per-pixel "warped in bounds" flags of a lane live in one 64-bit register (needs <= 64 chunks
+// per wave), else in an LDS ballot array.  TI / TD: storage type of the intensity+gradient planes / of the depth plane
+// (double = reference-exact).
+template <int T, bool SRC_LDS, bool OWNER_LDS, bool MASK_REG, typename TI, typename TD>
+__device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds &L, const int pair, const bool state_in_lds,
+                                           int &iteration, double &last_gnorm, int &last_valid)
 {
   constexpr int NW = T / WAVE;
-  extern __shared__ __align__(16) unsigned char lds_raw[];
-  // LDS carve-up (all offsets multiples of 8):
-  double *s_cst = reinterpret_cast<double *>(lds_raw);                 // [32]
-  double *s_state = s_cst + 32;                                        // [8]
-  double *s_red = s_state + 8;                                         // [NW][NRED]
-  int *s_ctl = reinterpret_cast<int *>(s_red + NW * NRED);             // [CTL_COUNT]
-  unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(s_ctl + CTL_COUNT);  // [n_chunks] (!MASK_REG)
-  unsigned char *p = reinterpret_cast<unsigned char *>(s_mask + (MASK_REG ? 0 : A.n_chunks));
-  int *s_owner = reinterpret_cast<int *>(p);                           // [n] (OWNER_LDS) or [n_lds] (owner map in HBM)
-  if (OWNER_LDS) p += sizeof(int) * (size_t)owner_lds_entries(A.n, T);
-  const int n_lds = OWNER_LDS ? 0 : A.n_lds;      // owner map in HBM: targets below n_lds are resolved in LDS all the same
-  double *s_i0 = reinterpret_cast<double *>(p);                        // [n]      (SRC_LDS)
-
+  double *const s_cst = L.cst, *const s_state = L.state, *const s_red = L.red, *const s_i0 = L.i0;
+  int *const s_ctl = L.ctl, *const s_owner = L.owner;
+  unsigned long long *const s_mask = L.mask;
   const int tid = threadIdx.x;
   const int lane = tid & (WAVE - 1);
   // wave-uniform by construction; saying so lets the chunk loops run on the scalar unit (s_cmp / s_cbranch)
   // instead of exec-masked vector compares
   const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
   const int n = A.n, W = A.w, H = A.h;
-  // Work queue: the grid has as many workgroups as fit the chip; each draws pair after pair from an atomic counter.
-  // Pairs stop after data-dependent iteration counts and the hardware deals blocks to the 8 XCDs round-robin, so a
-  // one-block-per-pair grid leaves whole XCDs idle while another one still works through its long pairs.
-  // Thread 0 draws the next index in the same block that writes the finished pair back, so that the only thing between
-  // the iteration loop and the barrier at the head of the work loop is one if-block (two adjacent `if (tid == 0)`
-  // blocks, one either side of the back edge, were threaded together by the compiler into a loop that reached that
-  // barrier with thread 0 parked: a hang).
-  // (draw_pair_any: with handover_in the pairs come from the list an earlier launch of this level left behind)
-  // The owner map in LDS is wiped ONCE per workgroup: pass 2 resets every slot it reads, and it reads all of them.
-  // It is padded to whole chunks plus one round of the workgroup (owner_lds_entries): pass 2 fetches the owner a chunk
-  // ahead without asking whether that chunk still exists -- the padding reads -1, "nobody", and pass 1 never writes there.
-  for (int k = tid; k < (OWNER_LDS ? owner_lds_entries(n, T) : n_lds); k += T) s_owner[k] = -1;
-  if (tid == 0) s_ctl[CTL_PAIR] = draw_pair_any(A);
-#ifdef PHOVO_STAMPS
-  // diagnostic build only: where the time between two pairs of a workgroup goes (100 MHz wall clock, thread 0's view)
-  unsigned gp_end = 0, gp_draw = 0, gp_top = 0, gp_state = 0, gp_cst = 0;
-#endif
-  for (;;) {
-  // The ticket thread 0 has just stored must have LEFT its LDS queue before any wave is released: the compiler omits
-  // the wait in front of this one barrier (it relies on LDS operations being ordered across waves), and on the GPU
-  // about one wave in 10^5 then read the previous ticket and aligned the wrong pair's pixels into this pair's sums --
-  // or, on the last round, would never have left the loop.  Found by test_work_queue_results_do_not_depend_on_...
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __syncthreads();
-  const int pair = __builtin_amdgcn_readfirstlane(s_ctl[CTL_PAIR]);
-  if (pair >= A.n_pairs) break;           // uniform: every wave of the workgroup leaves together
-#ifdef PHOVO_STAMPS
-  gp_top = (unsigned)wall_clock64();
-#endif
+  const int n_lds = OWNER_LDS ? 0 : A.n_lds;      // owner map in HBM: targets below n_lds are resolved in LDS all the same
 
   const unsigned char *src_frame = A.planes + (size_t)A.src[pair] * A.frame_bytes;
   const unsigned char *tgt_frame = A.planes + (size_t)A.tgt[pair] * A.frame_bytes;
@@ -108,6 +90,9 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
   const __amdgpu_buffer_rsrc_t rGY = plane_rsrc<TI>(tgt_frame + A.plane_off[PLANE_GY], n);
 
   // ---- level prologue -------------------------------------------------------------------
+  // (a level that follows another one in the same workgroup: every wave must have read the previous level's last
+  // CTL_DONE before wave 0 clears it below)
+  if (state_in_lds) __syncthreads();
   if (!OWNER_LDS) {
     // Owner map in HBM: entries carry the iteration they were written in (OWNER_TAG_SHIFT), so nothing has to be
     // reset between iterations; it is wiped once per pair here (the barrier below waits for the stores, and the
@@ -119,26 +104,16 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
     for (int k = tid; k < n; k += T) s_i0[k] = plane_load<TI>(rI0, k);
   }
   if (wave == 0) {
-    serial_priority(true);          // (gn_device.hpp: the other waves of the workgroup wait for this one)
     double st[6];
 #pragma unroll
-    for (int j = 0; j < 6; j++) st[j] = A.states[(size_t)pair * 6 + j];
-#ifdef PHOVO_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(st[0]), "+v"(st[1]), "+v"(st[2]), "+v"(st[3]), "+v"(st[4]), "+v"(st[5]) :: "memory");
-    gp_state = (unsigned)wall_clock64();
-#endif
+    for (int j = 0; j < 6; j++) st[j] = state_in_lds ? s_state[j] : A.states[(size_t)pair * 6 + j];
     write_pose_constants(st[0], st[1], st[2], st[3], st[4], st[5], s_cst, lane);
     if (lane == 0) {
 #pragma unroll
       for (int j = 0; j < 6; j++) s_state[j] = st[j];
       s_ctl[CTL_DONE] = 0;
-      s_ctl[CTL_FLAGS] = 0;
+      if (!state_in_lds) s_ctl[CTL_FLAGS] = 0;
     }
-#ifdef PHOVO_STAMPS
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    gp_cst = (unsigned)wall_clock64();
-#endif
-    serial_priority(false);
   }
   __syncthreads();
 
@@ -146,24 +121,11 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
   const double min_d = A.min_depth, max_d = A.max_depth;
   const double dW = (double)W, dH = (double)H;
   const double huber_delta = A.huber_delta;
-#ifdef PHOVO_AB_NO_HUBER          // A/B diagnostic build only (tools/): compiles the extension out
-  const bool huber_on = false;
-#else
   const bool huber_on = huber_delta > 0.0;
-#endif
 
   // A wave walks the image in chunks of 64 consecutive pixels, NW chunks apart; (row, column) of a
   // lane's pixel is carried along instead of divided out per pixel.
   const int k0 = wave * WAVE + lane;
-#ifdef PHOVO_AB_ROWCOL_CARRY       // A/B diagnostic build only (tools/): (row, column) carried with compare-and-wrap, round 2
-  const int r0 = k0 / W, c0 = k0 - r0 * W;
-  const int step_r = (NW * WAVE) / W, step_c = (NW * WAVE) - step_r * W;
-  const RowColStep rc_step = make_rowcol_step(step_r, step_c, W);
-  const double cd0 = (double)c0, rd0 = (double)r0;
-#define PHOVO_ROWCOL_BEGIN double cd = cd0, rd = rd0;
-#define PHOVO_ROWCOL_HERE
-#define PHOVO_ROWCOL_NEXT rowcol_advance(cd, rd, rc_step);
-#else
   // (row, column) of a lane's pixel from its linear index, carried as a double: four instructions per chunk (add, fma,
   // trunc, fma) instead of the six of a carried pair with compare-and-wrap, and two registers less across the loops
   const RowColFromIndex rc_map = make_rowcol_from_index(W);
@@ -171,28 +133,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
 #define PHOVO_ROWCOL_BEGIN double kd = kd0, cd, rd;
 #define PHOVO_ROWCOL_HERE rowcol_from_index(kd, rc_map, cd, rd);
 #define PHOVO_ROWCOL_NEXT kd += kd_step;
-#endif
 
-  int iteration = 0;                // continuing a pair an earlier launch handed over: its completed iterations count
-  if (A.handover_in) iteration = __builtin_amdgcn_readfirstlane(A.reports[pair].iterations[A.level]);
-  bool handed_over = false;
-  double last_gnorm = 0.0;
-  int last_valid = 0;
-#ifdef PHOVO_STAMPS
-  unsigned long long st_sum[5] = {0, 0, 0, 0, 0};
-  unsigned long long st_prev = clock64();
-  const unsigned long long st_begin = wall_clock64();       // 100 MHz, common to all CUs: when this pair's first iteration began
-#define PHOVO_STAMP(i) { unsigned long long _n = clock64(); st_sum[i] += _n - st_prev; st_prev = _n; }
-  // the serial section of wave 0 in three parts: cross-wave sum + broadcast, solve + update, pose constants
-  unsigned long long st_sub[3] = {0, 0, 0};
-  unsigned long long st_sub_prev = 0;
-#define PHOVO_SUBSTAMP_BEGIN { st_sub_prev = clock64(); }
-#define PHOVO_SUBSTAMP(i) { unsigned long long _n = clock64(); st_sub[i] += _n - st_sub_prev; st_sub_prev = _n; }
-#else
-#define PHOVO_STAMP(i)
-#define PHOVO_SUBSTAMP_BEGIN
-#define PHOVO_SUBSTAMP(i)
-#endif
   while (true) {
     // ---- constants of this iteration (uniform -> SGPRs) -----------------------------------
     const double cx = uniform_f64(s_cst[C_X]), cyy = uniform_f64(s_cst[C_Y]), cz = uniform_f64(s_cst[C_Z]);
@@ -334,9 +275,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
         }
       }
     }
-    PHOVO_STAMP(0)
     __syncthreads();
-    PHOVO_STAMP(1)
 
     // ---- pass 2: residual, Jacobian row, normal-equation accumulation ---------------------
     const double t4 = uniform_f64(s_cst[C_T4]), t5 = uniform_f64(s_cst[C_T5]), t6 = uniform_f64(s_cst[C_T6]);
@@ -468,7 +407,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
     // instructions per iteration instead of two scalar ones per chunk).
     acc[RED_VALID] = MASK_REG ? (double)(__popc((unsigned)inb_lo) + __popc((unsigned)inb_hi)) : (lane == 0 ? (double)n_rows : 0.0);
 
-    PHOVO_STAMP(2)
+
     // ---- wave-level transposed butterfly: 32 shuffles, lane l ends with value index idx(l) ----
     reduce_stage_swap<32, false>(acc);
     reduce_stage_swap<16, true>(acc);
@@ -486,12 +425,9 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
       if ((ln & 1) == 0) s_red[wave * NRED + idx] = total;
     }
     __syncthreads();
-    PHOVO_STAMP(3)
 
     // ---- wave 0: cross-wave sum (fixed order), solve, update, terminate ------------------------
     if (wave == 0) {
-      serial_priority(true);
-      PHOVO_SUBSTAMP_BEGIN
       // lane l sums value (l & 31) over half of the waves, the halves meet in one shuffle
       double v = 0.0;
       if constexpr (NW == 1) {
@@ -510,7 +446,6 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
       for (int i = 0; i < 6; i++) g[i] = __shfl(v, 21 + i, WAVE);
 
       last_valid = (int)__shfl(v, RED_VALID, WAVE);
-      PHOVO_SUBSTAMP(0)
       double step[6];
       solve6_ldlt(h, g, step);
       double st[6];
@@ -529,68 +464,148 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
       if (it >= A.max_iter) done = true;                                                // :383
       else if (gnorm < A.min_grad_norm) done = true;                                    // :388
       if (!finite) done = true;     // the reference would keep iterating on NaN; the result is the same NaN
-      // handover_out with a cap: a pair still running once it has done iter_cap iterations of the level leaves this
-      // launch here (its state is stored as after any other iteration) and is continued by the next launch of the level
-      const bool hand = !done && A.handover_out != nullptr && A.iter_cap > 0 && it >= A.iter_cap;
-      PHOVO_SUBSTAMP(1)
       if (!done) write_pose_constants(st[0], st[1], st[2], st[3], st[4], st[5], s_cst, lane);   // wave-uniform branch
-      PHOVO_SUBSTAMP(2)
       if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < 6; i++) s_state[i] = st[i];
-        s_ctl[CTL_DONE] = done ? 1 : (hand ? 2 : 0);
+        s_ctl[CTL_DONE] = done ? 1 : 0;
         if (!finite) s_ctl[CTL_FLAGS] |= (int)PHOVO_PAIR_NONFINITE;
         if (last_valid < 6) s_ctl[CTL_FLAGS] |= (int)PHOVO_PAIR_RANK_DEFICIENT;
       }
       last_gnorm = gnorm;
-      serial_priority(false);
     }
     __syncthreads();
-    PHOVO_STAMP(4)
     iteration++;
-    const int done_word = s_ctl[CTL_DONE];
-    if (done_word) { handed_over = done_word == 2; break; }
+    if (s_ctl[CTL_DONE]) break;
   }
+#undef PHOVO_ROWCOL_BEGIN
+#undef PHOVO_ROWCOL_HERE
+#undef PHOVO_ROWCOL_NEXT
+}
 
-  // ---- epilogue: state and report back to HBM -------------------------------------------------
-  if (wave == 0) serial_priority(true);       // (dropped again at the head of the next pair's prologue ... or by the exit)
-  if (tid == 0) {
-#pragma unroll
-    for (int j = 0; j < 6; j++) A.states[(size_t)pair * 6 + j] = s_state[j];
-    if (A.reports) {
-      A.reports[pair].iterations[A.level] = iteration;
-      A.reports[pair].gradient_norm = last_gnorm;
-      A.reports[pair].valid_pixels[A.level] = last_valid;
-      // (a flag is rare: an atomic without return instead of a read-modify-write that thread 0 would wait for)
-      const uint32_t new_flags = (uint32_t)s_ctl[CTL_FLAGS] | (A.handover_in ? A.takeover_flag : 0u);
-      if (new_flags) atomicOr(&A.reports[pair].flags, new_flags);
-#ifdef PHOVO_STAMPS
-      // diagnostic build only: phase cycle sums of wave 0 go to the otherwise unused report slots 8..12
-      for (int j = 0; j < 5; j++) A.reports[pair].iterations[8 + j] = (int)(st_sum[j] / (unsigned long long)iteration);
-      // slots 13..15 (last level launched wins): begin / end of the pair on the 100 MHz wall clock, and the workgroup
-      for (int j = 0; j < 3; j++) A.reports[pair].iterations[5 + j] = (int)(st_sub[j] / (unsigned long long)iteration);
-      A.reports[pair].iterations[13] = (int)(unsigned)st_begin;
-      A.reports[pair].iterations[14] = (int)(unsigned)wall_clock64();
-      A.reports[pair].iterations[15] = (int)blockIdx.x;
-      // the gap in front of THIS pair: end of the pair before (0: none), its draw done, loop-top barrier passed, state
-      // loaded, pose constants written; iterations[13] is the end of the prologue barrier
-      A.reports[pair].valid_pixels[8] = (int)gp_end;
-      A.reports[pair].valid_pixels[9] = (int)gp_draw;
-      A.reports[pair].valid_pixels[10] = (int)gp_top;
-      A.reports[pair].valid_pixels[11] = (int)gp_state;
-      A.reports[pair].valid_pixels[12] = (int)gp_cst;
-      gp_end = (unsigned)wall_clock64();
-#endif
-    }
-    if (handed_over) handover_append(A, pair);
-    s_ctl[CTL_PAIR] = draw_pair_any(A);
-#ifdef PHOVO_STAMPS
+
+// LDS carve-up of a workgroup of T threads whose largest level has n_max pixels in n_chunks_max chunks.
+template <int T, bool SRC_LDS, bool OWNER_LDS, bool MASK_REG>
+__device__ __forceinline__ LevelLds carve_lds(unsigned char *lds_raw, int n_max, int n_chunks_max)
+{
+  constexpr int NW = T / WAVE;
+  LevelLds L;
+  L.cst = reinterpret_cast<double *>(lds_raw);                            // [32]
+  L.state = L.cst + 32;                                                   // [8]
+  L.red = L.state + 8;                                                    // [NW][NRED]
+  L.ctl = reinterpret_cast<int *>(L.red + NW * NRED);                     // [CTL_COUNT]
+  L.mask = reinterpret_cast<unsigned long long *>(L.ctl + CTL_COUNT);     // [n_chunks] (!MASK_REG)
+  unsigned char *p = reinterpret_cast<unsigned char *>(L.mask + (MASK_REG ? 0 : n_chunks_max));
+  L.owner = reinterpret_cast<int *>(p);                                   // [n] (OWNER_LDS) or [n_lds] (owner map in HBM)
+  if (OWNER_LDS) p += sizeof(int) * (size_t)owner_lds_entries(n_max, T);
+  L.i0 = reinterpret_cast<double *>(p);                                   // [n]      (SRC_LDS)
+  return L;
+}
+
+// One level per launch.  WPS = waves per SIMD the register allocator must leave room for (2 workgroups of 512 threads
+// per CU <=> 4).
+// Work queue: the grid has as many workgroups as fit the chip; each draws pair after pair from an atomic counter.
+// Pairs stop after data-dependent iteration counts and the hardware deals blocks to the 8 XCDs round-robin, so a
+// one-block-per-pair grid leaves whole XCDs idle while another one still works through its long pairs.
+// Thread 0 draws the next index in the same block that writes the finished pair back, so that the only thing between
+// the iteration loop and the barrier at the head of the work loop is one if-block (two adjacent `if (tid == 0)`
+// blocks, one either side of the back edge, were threaded together by the compiler into a loop that reached that
+// barrier with thread 0 parked: a hang).
+// (draw_pair_any: with handover_in the pairs come from the list the sliding-window kernel left behind)
+// The owner map in LDS is wiped ONCE per workgroup: pass 2 resets every slot it reads, and it reads all of them.
+// It is padded to whole chunks plus one round of the workgroup (owner_lds_entries): pass 2 fetches the owner a chunk
+// ahead without asking whether that chunk still exists -- the padding reads -1, "nobody", and pass 1 never writes there.
+template <int T, int WPS, bool SRC_LDS, bool OWNER_LDS, bool MASK_REG, typename TI, typename TD>
+__global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
+{
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  const LevelLds L = carve_lds<T, SRC_LDS, OWNER_LDS, MASK_REG>(lds_raw, A.n, A.n_chunks);
+  int *const s_ctl = L.ctl;
+  const int tid = threadIdx.x;
+  for (int k = tid; k < (OWNER_LDS ? owner_lds_entries(A.n, T) : A.n_lds); k += T) L.owner[k] = -1;
+  if (tid == 0) s_ctl[CTL_PAIR] = draw_pair_any(A);
+  for (;;) {
+    // The ticket thread 0 has just stored must have LEFT its LDS queue before any wave is released: the compiler omits
+    // the wait in front of this one barrier (it relies on LDS operations being ordered across waves), and on the GPU
+    // about one wave in 10^5 then read the previous ticket and aligned the wrong pair's pixels into this pair's sums --
+    // or, on the last round, would never have left the loop.  Found by test_work_queue_results_do_not_depend_on_...
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    gp_draw = (unsigned)wall_clock64();
-#endif
-  }
+    __syncthreads();
+    const int pair = __builtin_amdgcn_readfirstlane(s_ctl[CTL_PAIR]);
+    if (pair >= A.n_pairs) break;           // uniform: every wave of the workgroup leaves together
+
+    int iteration = 0;                // continuing a pair the sliding-window kernel handed over: its completed iterations count
+    if (A.handover_in) iteration = __builtin_amdgcn_readfirstlane(A.reports[pair].iterations[A.level]);
+    double last_gnorm = 0.0;
+    int last_valid = 0;
+    level_body<T, SRC_LDS, OWNER_LDS, MASK_REG, TI, TD>(A, L, pair, false, iteration, last_gnorm, last_valid);
+
+    // ---- epilogue: state and report back to HBM -------------------------------------------------
+    if (tid == 0) {
+#pragma unroll
+      for (int j = 0; j < 6; j++) A.states[(size_t)pair * 6 + j] = L.state[j];
+      if (A.reports) {
+        A.reports[pair].iterations[A.level] = iteration;
+        A.reports[pair].gradient_norm = last_gnorm;
+        A.reports[pair].valid_pixels[A.level] = last_valid;
+        // (a flag is rare: an atomic without return instead of a read-modify-write that thread 0 would wait for)
+        const uint32_t new_flags = (uint32_t)s_ctl[CTL_FLAGS] | (A.handover_in ? A.takeover_flag : 0u);
+        if (new_flags) atomicOr(&A.reports[pair].flags, new_flags);
+      }
+      s_ctl[CTL_PAIR] = draw_pair_any(A);
+    }
   }   // next pair
 }
+
+// SEVERAL consecutive levels per launch: a workgroup draws a pair and runs it through F.n_levels levels, coarse to fine,
+// back to back -- the loop of Optimize() (:502-563) as the reference has it, per pair over levels.  The state stays in
+// LDS between levels; iteration counts and valid-pixel counts go to the pair's report level by level.  Why: with the
+// shipped thresholds a pair stops after a data-dependent number of iterations (:376-392), and one launch per level makes
+// every level boundary a boundary for the whole batch -- each persistent launch drains at falling occupancy and the few
+// pairs that run to max_num_iterations finish alone, once per level.  Here a long pair of one level runs beside other
+// pairs' work of any level, and the batch has ONE drain.  All levels take the geometry of the largest one (T threads,
+// owner map in LDS sized for F.n_max pixels, register masks): per level the arithmetic and its order are those of
+// gn_level_kernel<T, ...> with the same T, so the two paths are bit-identical (tests/test_gpu_fused.py).
+template <int T, int WPS, typename TI, typename TD>
+__global__ __launch_bounds__(T, WPS) void gn_fused_kernel(const GNFusedArgs F)
+{
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  const LevelLds L = carve_lds<T, false, true, true>(lds_raw, F.n_max, 0);
+  int *const s_ctl = L.ctl;
+  const int tid = threadIdx.x;
+  for (int k = tid; k < owner_lds_entries(F.n_max, T); k += T) L.owner[k] = -1;
+  if (tid == 0) s_ctl[CTL_PAIR] = draw_pair(F.work_counter, F.n_queues, F.n_pairs);
+  for (;;) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // see gn_level_kernel
+    __syncthreads();
+    const int pair = __builtin_amdgcn_readfirstlane(s_ctl[CTL_PAIR]);
+    if (pair >= F.n_pairs) break;           // uniform: every wave of the workgroup leaves together
+
+    double last_gnorm = 0.0;
+    for (int li = 0; li < F.n_levels; li++) {               // coarse to fine  :502-503
+      const GNLevelArgs &A = F.lv[li];
+      int iteration = 0, last_valid = 0;
+      level_body<T, false, true, true, TI, TD>(A, L, pair, li > 0, iteration, last_gnorm, last_valid);
+      if (tid == 0 && A.reports) {
+        A.reports[pair].iterations[A.level] = iteration;
+        A.reports[pair].valid_pixels[A.level] = last_valid;
+      }
+    }
+
+    if (tid == 0) {
+      const GNLevelArgs &A = F.lv[0];
+#pragma unroll
+      for (int j = 0; j < 6; j++) A.states[(size_t)pair * 6 + j] = L.state[j];
+      if (A.reports) {
+        A.reports[pair].gradient_norm = last_gnorm;
+        const uint32_t new_flags = (uint32_t)s_ctl[CTL_FLAGS];
+        if (new_flags) atomicOr(&A.reports[pair].flags, new_flags);
+      }
+      s_ctl[CTL_PAIR] = draw_pair(F.work_counter, F.n_queues, F.n_pairs);
+    }
+  }   // next pair
+}
+
 
 // EXTENSION, NOT IN THE REFERENCE'S ANALYTIC PATH (PHOVO_SAMPLING_BILINEAR): forward-additive alignment with
 // bilinear sampling.  Every valid source pixel i is warped to the real-valued (tr, tc); the target intensity and
@@ -847,16 +862,17 @@ static_assert((1 << OWNER_TAG_SHIFT) - 1 == OWNER_INDEX_MASK, "index mask and ta
 //   HUGE   1024 threads, owner map in global memory, ballot mask in LDS
 //   TINY   256 threads, 4 workgroups/CU, everything in LDS (levels of <= 2048 pixels)
 //   QUAD   256 threads, 4 workgroups/CU, owner map in LDS, source intensity gathered from L2
-enum Variant { V_TINY = 0, V_MID, V_WIDE, V_HUGE, V_QUAD, V_DUO, V_SOLO };
+enum Variant { V_TINY = 0, V_MID, V_WIDE, V_HUGE, V_QUAD, V_SOLO };
 
 // ... times the three plane storages (fp64 = reference-exact; fp32; fp16 images + fp32 depth).
+//   SOLO   64 threads, 16 workgroups/CU: one wave per pair (levels of <= 2048 pixels in a throughput launch)
 #define PHOVO_KERNEL_TINY(TI, TD)  gn_level_kernel<256, 4, true, true, true, TI, TD>
 #define PHOVO_KERNEL_MID(TI, TD)   gn_level_kernel<512, 4, false, true, true, TI, TD>
 #define PHOVO_KERNEL_WIDE(TI, TD)  gn_level_kernel<1024, 4, false, true, true, TI, TD>
 #define PHOVO_KERNEL_HUGE(TI, TD)  gn_level_kernel<1024, 4, false, false, false, TI, TD>
 #define PHOVO_KERNEL_QUAD(TI, TD)  gn_level_kernel<256, 4, false, true, true, TI, TD>
-#define PHOVO_KERNEL_DUO(TI, TD)   gn_level_kernel<512, 4, true, true, true, TI, TD>
 #define PHOVO_KERNEL_SOLO(TI, TD)  gn_level_kernel<64, 4, false, true, true, TI, TD>
+#define PHOVO_KERNEL_FUSED(TI, TD) gn_fused_kernel<512, 4, TI, TD>
 
 }  // namespace
 
@@ -869,9 +885,8 @@ bool gn_plan_level(int n, GNLaunchPlan *plan, int prefer_latency)
   // Levels of <= 2048 pixels in a throughput launch: ONE WAVE per pair, 16 workgroups per CU.  An iteration of such a level
   // is short (40x30: 19 chunks) and a third of a 256-thread workgroup's time per iteration is wave 0's serial section
   // (solve, sincos, pose constants) with the other three waves waiting at the barrier; with one wave per pair nobody
-  // waits -- the other 15 pairs of the CU fill the SIMDs meanwhile.  PHOVO_GN_NO_SOLO=1: A/B switch for tools/.
-  static const bool no_solo = std::getenv("PHOVO_GN_NO_SOLO") != nullptr;
-  if (n <= 2048 && !prefer_latency && !no_solo && n_chunks <= 64) {
+  // waits -- the other 15 pairs of the CU fill the SIMDs meanwhile.
+  if (n <= 2048 && !prefer_latency && !tuning_switch("PHOVO_GN_NO_SOLO") && n_chunks <= 64) {
     plan->variant = V_SOLO; plan->threads = 64; plan->wgs_per_cu = 16; plan->owner_in_lds = true; plan->source_in_lds = false;
     plan->lds_bytes = (int)(lds_fixed_bytes(64) + owner_bytes(64));
     return true;
@@ -884,27 +899,17 @@ bool gn_plan_level(int n, GNLaunchPlan *plan, int prefer_latency)
   const size_t f256 = lds_fixed_bytes(256);
   // Four 256-thread workgroups per CU beat two of 512 on levels this small (80x60: 4.31 vs 4.64 ms per
   // 2048 pairs x 50 iterations): while one workgroup's wave 0 solves, three others keep the SIMDs busy.
-  // PHOVO_GN_NO_QUAD=1 is a tuning aid for tools/ only.
-  static const bool no_quad = std::getenv("PHOVO_GN_NO_QUAD") != nullptr;
   // (one pair alone on a CU: 12.4 us per 80x60 iteration with 256 threads, 10.1 us with 512 -- prefer_latency)
-  // experiment (tools/ only): two 512-thread workgroups per CU with the source intensity plane staged in LDS
-  static const bool duo = std::getenv("PHOVO_GN_DUO") != nullptr;
-  if (duo && !prefer_latency && n_chunks <= 64 * 8 && lds_fixed_bytes(512) + owner_bytes(512) + src <= LDS_HALF) {
-    plan->variant = V_DUO; plan->threads = 512; plan->wgs_per_cu = 2; plan->owner_in_lds = true; plan->source_in_lds = true;
-    plan->lds_bytes = (int)(lds_fixed_bytes(512) + owner_bytes(512) + src);
-    return true;
-  }
-  if (!no_quad && !prefer_latency && n_chunks <= 64 * 4 && f256 + owner_bytes(256) <= LDS_LIMIT / 4) {
+  if (!tuning_switch("PHOVO_GN_NO_QUAD") && !prefer_latency && n_chunks <= 64 * 4 && f256 + owner_bytes(256) <= LDS_LIMIT / 4) {
     plan->variant = V_QUAD; plan->threads = 256; plan->wgs_per_cu = 4; plan->owner_in_lds = true; plan->source_in_lds = false;
     plan->lds_bytes = (int)(f256 + owner_bytes(256));
     return true;
   }
   const size_t f512 = lds_fixed_bytes(512), f1024 = lds_fixed_bytes(1024);
   const bool reg512 = n_chunks <= 64 * 8, reg1024 = n_chunks <= 64 * 16;
-  static const bool force_wide = std::getenv("PHOVO_GN_FORCE_WIDE") != nullptr;     // tuning aid
   // prefer_latency == 2: the widest workgroup that keeps the owner map in LDS (a pair alone on its CU: 16 waves instead of 8)
   const bool widest = prefer_latency >= 2 && reg1024 && f1024 + owner_bytes(1024) <= LDS_LIMIT && n_chunks >= 64;
-  if (!force_wide && !widest && reg512 && f512 + owner_bytes(512) <= LDS_HALF) {
+  if (!tuning_switch("PHOVO_GN_FORCE_WIDE") && !widest && reg512 && f512 + owner_bytes(512) <= LDS_HALF) {
     plan->variant = V_MID; plan->threads = 512; plan->wgs_per_cu = 2; plan->owner_in_lds = true; plan->source_in_lds = false;
     plan->lds_bytes = (int)(f512 + owner_bytes(512));
     return true;
@@ -918,13 +923,33 @@ bool gn_plan_level(int n, GNLaunchPlan *plan, int prefer_latency)
   if (f1024 + mask > LDS_LIMIT) return false;
   if (n > OWNER_INDEX_MASK) return false;          // the tagged entries of the HBM owner map hold 21-bit indices
   // whatever LDS the ballot masks leave free holds the leading part of the owner map (whole 64-pixel chunks)
-  static const bool no_split = std::getenv("PHOVO_GN_NO_OWNER_SPLIT") != nullptr;      // tuning aid for tools/
   const size_t spare = LDS_LIMIT - f1024 - mask;
-  plan->owner_lds_entries = no_split ? 0 : (int)((spare / sizeof(int)) / WAVE * WAVE);
+  plan->owner_lds_entries = tuning_switch("PHOVO_GN_NO_OWNER_SPLIT") ? 0 : (int)((spare / sizeof(int)) / WAVE * WAVE);
   if (plan->owner_lds_entries > n) plan->owner_lds_entries = (n / WAVE) * WAVE;
   plan->variant = V_HUGE; plan->threads = 1024; plan->wgs_per_cu = 1; plan->owner_in_lds = false; plan->source_in_lds = false;
   plan->lds_bytes = (int)(f1024 + mask + sizeof(int) * (size_t)plan->owner_lds_entries);
   return true;
+}
+
+bool gn_level_fusable(int n)
+{
+  const size_t n_chunks = (size_t)(n + WAVE - 1) / WAVE;
+  return n > 2048 && n_chunks <= 64 * 8 &&
+         lds_fixed_bytes(512) + sizeof(int) * (size_t)owner_lds_entries(n, 512) <= LDS_HALF;
+}
+
+bool gn_plan_fused_geometry(int n, GNLaunchPlan *plan)
+{
+  if (!gn_level_fusable(n)) return false;
+  plan->variant = V_MID; plan->threads = 512; plan->wgs_per_cu = 2; plan->owner_in_lds = true; plan->source_in_lds = false;
+  plan->owner_lds_entries = 0;
+  plan->lds_bytes = gn_fused_lds_bytes(n);
+  return true;
+}
+
+int gn_fused_lds_bytes(int n_max)
+{
+  return (int)(lds_fixed_bytes(512) + sizeof(int) * (size_t)owner_lds_entries(n_max, 512));
 }
 
 template <typename TI, typename TD>
@@ -940,8 +965,8 @@ hipError_t prepare_storage()
   PHOVO_PREP(PHOVO_KERNEL_WIDE)
   PHOVO_PREP(PHOVO_KERNEL_HUGE)
   PHOVO_PREP(PHOVO_KERNEL_QUAD)
-  PHOVO_PREP(PHOVO_KERNEL_DUO)
   PHOVO_PREP(PHOVO_KERNEL_SOLO)
+  PHOVO_PREP(PHOVO_KERNEL_FUSED)
 #undef PHOVO_PREP
   return hipSuccess;
 }
@@ -957,10 +982,17 @@ hipError_t launch_storage(const GNLevelArgs &a, const GNLaunchPlan &plan, int n_
     case V_WIDE:  hipLaunchKernelGGL(PHOVO_KERNEL_WIDE(TI, TD), grid, block, lds, stream, a); break;
     case V_HUGE:  hipLaunchKernelGGL(PHOVO_KERNEL_HUGE(TI, TD), grid, block, lds, stream, a); break;
     case V_QUAD:  hipLaunchKernelGGL(PHOVO_KERNEL_QUAD(TI, TD), grid, block, lds, stream, a); break;
-    case V_DUO:   hipLaunchKernelGGL(PHOVO_KERNEL_DUO(TI, TD), grid, block, lds, stream, a); break;
     case V_SOLO:  hipLaunchKernelGGL(PHOVO_KERNEL_SOLO(TI, TD), grid, block, lds, stream, a); break;
     default: return hipErrorInvalidValue;
   }
+  return hipGetLastError();
+}
+
+template <typename TI, typename TD>
+hipError_t launch_fused_storage(const GNFusedArgs &f, int n_blocks, hipStream_t stream)
+{
+  hipLaunchKernelGGL(PHOVO_KERNEL_FUSED(TI, TD), dim3((unsigned)n_blocks), dim3(512), (size_t)gn_fused_lds_bytes(f.n_max),
+                     stream, f);
   return hipGetLastError();
 }
 
@@ -1016,6 +1048,22 @@ hipError_t gn_launch_level(const GNLevelArgs &a, const GNLaunchPlan &plan, int s
     case PHOVO_STORAGE_F64: return launch_storage<double, double>(a, plan, n_pairs, stream);
     case PHOVO_STORAGE_F32: return launch_storage<float, float>(a, plan, n_pairs, stream);
     case PHOVO_STORAGE_F16: return launch_storage<__half, float>(a, plan, n_pairs, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t gn_launch_fused(const GNFusedArgs &f, int storage, int cu_count, hipStream_t stream)
+{
+  if (f.n_pairs <= 0 || f.n_levels <= 0) return hipSuccess;
+  if (f.n_levels > GN_MAX_FUSED_LEVELS) return hipErrorInvalidValue;
+  for (int i = 0; i < f.n_levels; i++)
+    if (!gn_level_fusable(f.lv[i].n) || f.lv[i].n > f.n_max) return hipErrorInvalidValue;
+  const int slots = cu_count * 2;                                              // two 512-thread workgroups per CU
+  const int n_blocks = f.n_pairs < slots ? f.n_pairs : slots;
+  switch (storage) {
+    case PHOVO_STORAGE_F64: return launch_fused_storage<double, double>(f, n_blocks, stream);
+    case PHOVO_STORAGE_F32: return launch_fused_storage<float, float>(f, n_blocks, stream);
+    case PHOVO_STORAGE_F16: return launch_fused_storage<__half, float>(f, n_blocks, stream);
     default: return hipErrorInvalidValue;
   }
 }

@@ -37,32 +37,27 @@ struct GNLevelArgs {
   int *work_counter;        // [QUEUES_PER_LEVEL] heads QUEUE_HEAD_STRIDE ints apart, zeroed before the launch: workgroups draw pair indices from them
   int n_queues;             // 1: one queue for the whole grid; 8: one per XCD over a contiguous eighth of the pairs (+ stealing)
   int n_lds;                // owner map in HBM only: its first n_lds entries (a multiple of 64) live in LDS instead
-  // Hand-over of unfinished pairs from one launch of a level to the next (all on the same stream).  A list is
-  // [n_pairs + 1] ints, zeroed before the first launch: pair indices, and at [n_pairs] their number.
-  //   handover_out  non-null: a pair this launch does not finish is appended there (its state and its completed iteration
-  //                 count, reports[p].iterations[level], are in place)
-  //   iter_cap      with handover_out, > 0: a pair that has not terminated once it has done iter_cap iterations of the
-  //                 level is handed over (0: no cap -- the sliding-window kernel hands over for its own reason)
+  // Hand-over of pairs from the sliding-window launch of a level to the exact launch right behind it (same stream).  A
+  // list is [n_pairs + 1] ints, zeroed before the first launch: pair indices, and at [n_pairs] their number.
+  //   handover_out  non-null (sliding-window kernel): a pair whose warp leaves the window is appended there (its state and
+  //                 its completed iteration count, reports[p].iterations[level], are in place)
   //   handover_in   non-null: the launch works on that list instead of the pairs 0..n_pairs-1 and continues every pair at
   //                 its stored iteration count; takeover_flag is OR-ed into reports[p].flags of every pair taken
-  //                 (PHOVO_PAIR_WINDOW_FALLBACK or 0)
   const int *handover_in;
   int *handover_out;
-  int iter_cap;
   unsigned takeover_flag;
-  // The long pairs' chain (engine.cpp, enqueue): a pair a capped first launch hands over is MARKED and from then on runs on
-  // a second stream, beside the first launches of the later levels on the engine's stream.
-  //   mark_out    non-null: a pair appended to handover_out also gets mark_out[pair] = 1 (zeroed per enqueue)
-  //   skip_marks  non-null (plain queue only): a drawn pair with skip_marks[pair] != 0 is not this launch's -- it is
-  //               drawn past (the side launch of the level takes the marked pairs from the cumulative side list)
-  //   side_out    non-null, with mark_out: a pair that gets its mark for the FIRST time is also appended to this cumulative
-  //               list (pair indices, number at [n_pairs]) -- the pairs the second stream runs from the next level on
-  //   handover_count  non-null, with handover_in: the launch takes that many entries of the list (a snapshot taken on
-  //               the stream earlier) instead of its current length at [n_pairs]
-  int *mark_out;
-  const int *skip_marks;
-  int *side_out;
-  const int *handover_count;
+};
+
+// Several consecutive levels of one launch (gn_fused_kernel): lv[0] is the coarsest.  The pair list, states, reports and
+// the queue are those of lv[0]; every level shares them.
+constexpr int GN_MAX_FUSED_LEVELS = 3;
+struct GNFusedArgs {
+  GNLevelArgs lv[GN_MAX_FUSED_LEVELS];
+  int n_levels;
+  int n_max;                // pixels of the largest level: sizes the owner map in LDS
+  int n_pairs;
+  int n_queues;
+  int *work_counter;
 };
 
 constexpr int QUEUES_PER_LEVEL = 8;      // one per XCD
@@ -87,6 +82,12 @@ bool gn_plan_level(int n, GNLaunchPlan *plan, int prefer_latency = 0);
 // args.n_pairs pairs, args.work_counter zeroed on the stream beforehand; the grid is min(pairs, CUs x workgroups/CU).
 hipError_t gn_launch_level(const GNLevelArgs &args, const GNLaunchPlan &plan, int storage, int cu_count,
                            hipStream_t stream);
+// Several consecutive levels in ONE persistent launch (a pair flows through them inside the workgroup that drew it): every
+// level must be gn_level_fusable (owner map in LDS beside a second 512-thread workgroup on the CU).
+bool gn_level_fusable(int n_pixels);
+int gn_fused_lds_bytes(int n_max);
+bool gn_plan_fused_geometry(int n_pixels, GNLaunchPlan *plan);      // the per-level kernel in the fused launch's geometry
+hipError_t gn_launch_fused(const GNFusedArgs &args, int storage, int cu_count, hipStream_t stream);
 // Extension (PHOVO_SAMPLING_BILINEAR): single-pass kernel, 256 threads, no owner map, any level size.
 hipError_t gn_launch_level_bilinear(const GNLevelArgs &args, int storage, bool corrected, int cu_count,
                                     hipStream_t stream);
@@ -124,6 +125,14 @@ hipError_t pyr_load_plane(const unsigned char *src, int n, double *dst, int stor
 hipError_t pyr_gaussian_blur(double *img, double *tmp, int w, int h, int ksize,
                              const double *d_kernel, hipStream_t stream);
 hipError_t fill_i32(int *dst, size_t n, int value, hipStream_t stream);
+
+// Diagnostic switches read from the environment exist only in a -DPHOVO_TUNING build (tools/); the release library reads
+// PHOVO_VISUALIZE_DIR and nothing else.
+#ifdef PHOVO_TUNING
+bool tuning_switch(const char *name);
+#else
+inline bool tuning_switch(const char *) { return false; }
+#endif
 
 // Error plumbing
 void set_last_error(const std::string &msg);

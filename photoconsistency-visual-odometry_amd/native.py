@@ -63,6 +63,17 @@ class PairReport(C.Structure):
     ]
 
 
+FUSION_AUTO, FUSION_OFF, FUSION_SPLIT = 0, -1, -2
+LAUNCH_KINDS = ("persistent", "fused", "slide", "slide_fallback", "wide", "bilinear")
+
+
+class LaunchRecord(C.Structure):
+    _fields_ = [
+        ("level_first", C.c_int), ("level_last", C.c_int), ("kind", C.c_int),
+        ("threads", C.c_int), ("lds_bytes", C.c_int), ("workgroups", C.c_int),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/phovo_hip.h declares
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -107,7 +118,7 @@ SYMBOLS = {
     "phovo_engine_set_depth_range": (C.c_int, [_vp, C.c_double, C.c_double]),
     "phovo_engine_set_build_all_levels": (C.c_int, [_vp, C.c_int]),
     "phovo_engine_set_wide_policy": (C.c_int, [_vp, C.c_int]),
-    "phovo_engine_set_iteration_cap": (C.c_int, [_vp, C.c_int]),
+    "phovo_engine_set_level_fusion": (C.c_int, [_vp, C.c_int]),
     "phovo_engine_set_batch_invariant": (C.c_int, [_vp, C.c_int]),
     "phovo_engine_set_slide_policy": (C.c_int, [_vp, C.c_int]),
     "phovo_engine_level_uses_wide": (C.c_int, [_vp, C.c_int, C.c_int]),
@@ -129,6 +140,7 @@ SYMBOLS = {
     "phovo_engine_results_device_ptr": (C.c_int, [_vp, C.POINTER(_vp)]),
     "phovo_engine_last_align_ms": (C.c_int, [_vp, _dp, _dp]),
     "phovo_engine_level_launch_info": (C.c_int, [_vp, C.c_int, _ip, _ip, _ip, _ip]),
+    "phovo_engine_last_launches": (C.c_int, [_vp, _vp, C.c_int, _ip]),
 }
 
 
@@ -158,6 +170,8 @@ def lib():
             build()
         L = C.CDLL(_SO)
         for name, (res, args) in SYMBOLS.items():
+            if os.environ.get("PHOVO_HIP_LIBRARY") and not hasattr(L, name):
+                continue                     # a diagnostic / older build named explicitly (tools/ A-B runs): bind what it has
             fn = getattr(L, name)            # AttributeError if the ABI and the header diverge
             fn.restype = res
             fn.argtypes = args

@@ -206,11 +206,11 @@ class AlignmentEngine:
         """0 automatic, 1 wide form wherever possible, -1 persistent form only."""
         check(self._lib.phovo_engine_set_wide_policy(self._h, int(policy)), "phovo_engine_set_wide_policy")
 
-    def set_iteration_cap(self, cap):
-        """Shipped thresholds: pairs still running after `cap` iterations of a level are finished by a second (and third)
-        launch (default 4; 0 = one launch).  Iteration counts are identical either way, poses agree within the parity
-        bar (the later launches use another geometry: last bits differ unless PHOVO_GN_TAIL_SAME_PLAN=1)."""
-        check(self._lib.phovo_engine_set_iteration_cap(self._h, int(cap)), "phovo_engine_set_iteration_cap")
+    def set_level_fusion(self, mode):
+        """native.FUSION_AUTO (default): consecutive levels that fit the 512-thread scatter kernel are ONE launch when a
+        gradient threshold makes their iteration counts data-dependent; FUSION_OFF: one launch per level; FUSION_SPLIT: one
+        launch per level in the fused launch's geometry (bit-identical to AUTO)."""
+        check(self._lib.phovo_engine_set_level_fusion(self._h, int(mode)), "phovo_engine_set_level_fusion")
 
     def set_batch_invariant(self, on=True):
         """Every batch, whatever its size, takes the same kernels and geometries: a pair's result does not depend on how
@@ -349,3 +349,16 @@ class AlignmentEngine:
         check(self._lib.phovo_engine_level_launch_info(self._h, int(level), C.byref(t), C.byref(l),
                                                        C.byref(o), C.byref(s)), "phovo_engine_level_launch_info")
         return dict(threads=t.value, lds_bytes=l.value, owner_in_lds=bool(o.value), source_in_lds=bool(s.value))
+
+    def last_launches(self):
+        """The kernel launches of the last enqueue, in order: dicts with levels (coarse to fine), kind, threads,
+        lds_bytes, workgroups."""
+        if not hasattr(self._lib, "phovo_engine_last_launches"):      # an older build under PHOVO_HIP_LIBRARY (tools/)
+            return []
+        cap = 4 * native.MAX_LEVELS
+        recs = (native.LaunchRecord * cap)()
+        n = C.c_int()
+        check(self._lib.phovo_engine_last_launches(self._h, C.cast(recs, C.c_void_p), cap, C.byref(n)),
+              "phovo_engine_last_launches")
+        return [dict(levels=list(range(r.level_first, r.level_last - 1, -1)), kind=native.LAUNCH_KINDS[r.kind],
+                     threads=r.threads, lds_bytes=r.lds_bytes, workgroups=r.workgroups) for r in recs[:min(n.value, cap)]]

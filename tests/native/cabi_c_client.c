@@ -60,7 +60,7 @@ int main(int argc, char **argv)
   CHECK(phovo_odometry_optimize(NULL) == PHOVO_E_INVALID_ARGUMENT);
   CHECK(phovo_engine_align_pairs(NULL, 0, NULL, NULL, NULL, NULL, NULL) == PHOVO_E_INVALID_ARGUMENT);
   CHECK(phovo_engine_upload_frames_u16(NULL, 0, 0, 0, NULL, 0, 0, NULL, 0, 0, 1.0) == PHOVO_E_INVALID_ARGUMENT);
-  CHECK(phovo_engine_set_iteration_cap(NULL, 4) == PHOVO_E_INVALID_ARGUMENT);
+  CHECK(phovo_engine_set_level_fusion(NULL, PHOVO_FUSION_OFF) == PHOVO_E_INVALID_ARGUMENT);
   CHECK(phovo_engine_set_slide_policy(NULL, 0) == PHOVO_E_INVALID_ARGUMENT);
   CHECK(phovo_engine_destroy(NULL) == PHOVO_OK && phovo_odometry_destroy(NULL) == PHOVO_OK);
   printf("cabi_c_client ok\n");

@@ -90,47 +90,3 @@ def test_two_gloo_ranks_share_the_gpu_and_print_one_contract_line():
     assert d["value"] > 0 and d["nonfinite_pairs"] == 0 and d["cpu_baseline"] is None
     assert abs(d["value"] - 512 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
     assert "rank 0/2 joined the gloo group" in r.stderr and "rank 1/2 joined the gloo group" in r.stderr
-
-
-def test_per_launch_work_accounting_conserves_the_pair_iterations():
-    """bench.py restates the engine's launch schedule of a thresholded enqueue (csrc/engine.cpp) to give every launch its
-    share of the algorithmic bytes (tools/shipped_profile.py divides them by the traced durations).  Whatever the
-    schedule, every pair-iteration belongs to exactly one launch, the launches come in host order, and with overlapping
-    levels the two first launches of a level split its pairs by what the level before handed over."""
-    import importlib.util
-    import numpy as np
-    spec = importlib.util.spec_from_file_location("bench_module", BENCH)
-    bench = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(bench)
-    rng = np.random.RandomState(5)
-    sizes, max_iter, min_grad = [307200, 76800, 19200, 4800, 1200], [0, 0, 5, 20, 50], [300.0] * 5
-    it = np.ones((1000, 5), dtype=np.int64)
-    for l in (2, 3, 4):
-        it[:, l] = np.minimum(rng.geometric(0.35, size=1000), max_iter[l])
-    old = {k: os.environ.pop(k, None) for k in ("PHOVO_GN_ITER_CAP", "PHOVO_GN_TAIL_STAGES", "PHOVO_GN_OVERLAP")}
-    try:
-        work = bench.capped_launch_work(it, sizes, max_iter, min_grad, 40.0)
-        os.environ["PHOVO_GN_OVERLAP"] = "0"
-        serial = bench.capped_launch_work(it, sizes, max_iter, min_grad, 40.0)
-    finally:
-        for k, v in old.items():
-            os.environ.pop(k, None)
-            if v is not None:
-                os.environ[k] = v
-    for sched in (work, serial):
-        for l in (2, 3, 4):
-            assert sum(w["pair_iterations"] for w in sched if w["level"] == l) == int(it[:, l].sum())
-            assert abs(sum(w["algorithmic_bytes"] for w in sched if w["level"] == l) - 40.0 * sizes[l] * it[:, l].sum()) < 1.0
-        assert [w["level"] for w in sched] == sorted((w["level"] for w in sched), reverse=True)      # coarse to fine
-    # level 4 (1200 px, 50 > cap): first + one follow-up; level 3 behind it: two first launches + one follow-up;
-    # level 2 (max 5 > cap 4, not > 12): two first launches + one follow-up
-    assert [w["level"] for w in work] == [4, 4, 3, 3, 3, 2, 2, 2]
-    assert [w["level"] for w in serial] == [4, 4, 3, 3, 2, 2]
-    l3 = [w for w in work if w["level"] == 3]
-    assert l3[0]["pairs"] + l3[1]["pairs"] == 1000 and l3[1]["pairs"] == int((it[:, 4] > 4).sum())
-    # the side list is cumulative: level 2's side launch takes what level 4 AND level 3 handed over
-    l2 = [w for w in work if w["level"] == 2]
-    assert l2[1]["pairs"] == int(((it[:, 4] > 4) | (it[:, 3] > 4)).sum()) and l2[0]["pairs"] + l2[1]["pairs"] == 1000
-    # a level of >= 16384 pixels whose max_num_iterations exceeds 3 x cap gets three launches (the 4-level configuration)
-    four = bench.capped_launch_work(it[:, :4], sizes[:4], [0, 0, 20, 50], min_grad[:4], 40.0)
-    assert [w["level"] for w in four] == [3, 3, 2, 2, 2, 2]

@@ -776,62 +776,6 @@ def test_exact_half_pixel_projections_on_the_device(sign, size, pairs):
         assert se3.state_distance(s[k], es) < POSE_TOL, (k, se3.state_distance(s[k], es))
 
 
-def test_iteration_cap_hand_over_leaves_results_unchanged(monkeypatch):
-    """With the shipped thresholds and more pairs than workgroup slots a level runs as two launches: every pair for at most
-    `cap` iterations, then the unfinished ones, all started together, from their stored state and iteration count
-    (engine.cpp).  2500 mixed pairs -- problems that stop after 1-3 iterations next to ones that
-    need more than the cap -- with the hand-over off (cap 0), at the default cap, at a cap of 1 (every pair that iterates
-    twice is handed over) and at 7: identical iteration counts everywhere, every copy of a problem bit-identical within a
-    run, poses equal to the oracle (...Analytic.h:376-392,547-549).  The second launch takes the geometry that runs one pair
-    fastest (1024 threads where the first had 512 or 256), so between caps the sums differ in their last bits (same bar as
-    against the oracle); with PHOVO_GN_TAIL_SAME_PLAN=1 it is the same kernel and everything is bit for bit the same."""
-    ncfg = native.read_config_file(os.path.join(CFG_DIR, "config_4_level_optimization_analytic.yml"))
-    nl = ncfg.num_levels
-    max_iter, min_grad = list(ncfg.max_num_iterations[:nl]), list(ncfg.min_gradient_norm[:nl])
-    _, ocfg = _cfgs(nl, max_iter, min_grad)
-    probs = [synthetic.make_pair(21, 640, 480, holes=0.02, trans=0.004, rot=0.002),
-             synthetic.make_pair(22, 640, 480, holes=0.0, trans=0.03, rot=0.015),
-             synthetic.make_pair(23, 640, 480, holes=0.05, trans=0.06, rot=0.03),
-             synthetic.make_pair(24, 640, 480, holes=0.01, trans=0.09, rot=0.05)]
-    expect = [oracle.align_frames(ocfg, p["K"], p["gray0"], p["depth0"], p["gray1"]) for p in probs]
-    its = [e[1] for e in expect]
-    assert max(i[2] for i in its) > 4 or max(i[3] for i in its) > 4, its      # somebody outlives the default cap
-    order = np.random.RandomState(9).randint(0, len(probs), size=2500)
-    src, tgt = [2 * int(i) for i in order], [2 * int(i) + 1 for i in order]
-
-    def run(caps):
-        out = {}
-        with odometry.AlignmentEngine() as eng:
-            eng.set_config(ncfg)
-            eng.set_intrinsic_matrix(probs[0]["K"])
-            eng.reserve_frames(2 * len(probs), 640, 480)
-            for i, p in enumerate(probs):
-                eng.upload_frame(2 * i, p["gray0"], p["depth0"], roles=native.ROLE_SOURCE)
-                eng.upload_frame(2 * i + 1, p["gray1"], None, roles=native.ROLE_TARGET)
-            for cap in caps:
-                eng.set_iteration_cap(cap)
-                out[cap] = eng.align_pairs(src, tgt, want_reports=True)
-        return out
-
-    out = run((0, 4, 1, 7))
-    first = {int(i): pos for pos, i in reversed(list(enumerate(order)))}
-    for cap, (sc, rc) in out.items():
-        for pos, i in enumerate(order):
-            es, eits = expect[int(i)]
-            assert list(rc[pos].iterations[:nl]) == eits, (cap, pos)
-            assert rc[pos].flags == 0
-            assert np.array_equal(sc[pos], sc[first[int(i)]]), (cap, pos)            # position and history do not matter
-        for i, pos in first.items():
-            assert se3.state_distance(sc[pos], expect[i][0]) < POSE_TOL, (cap, i)
-    # the same kernel in both launches: bit for bit whatever the cap
-    monkeypatch.setenv("PHOVO_GN_TAIL_SAME_PLAN", "1")
-    same = run((0, 4, 1))
-    for cap in (4, 1):
-        assert np.array_equal(same[cap][0], same[0][0]), cap
-        assert all(a.gradient_norm == b.gradient_norm for a, b in zip(same[cap][1], same[0][1]))
-    assert np.array_equal(same[0][0], out[0][0])
-
-
 def test_randomised_sweep_against_oracle():
     """tests/tools/fuzz_parity.py: 80 random problems (odd sizes, 1-3 levels, perturbed intrinsics, NaN / negative /
     out-of-range depth, large motions, non-zero initial states, 1 / 3 / 40 pairs), each held to the 1e-9 pose bar and

@@ -315,59 +315,6 @@ def test_rank_deficient_normal_equations_are_flagged_or_agree(n_valid):
 
 
 # ---------------------------------------------------------------------------------------------
-# consecutive levels overlap on two streams: same results as on one
-# ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("yml", ["config_4_level_optimization_analytic.yml", "config_5_level_optimization_analytic.yml"])
-def test_overlapping_levels_change_nothing_but_the_clock(yml, monkeypatch):
-    """With the shipped thresholds the pairs a capped first launch hands over (the few long ones) belong to a second
-    stream from then on -- their follow-up launches and their share of every later level (a side launch per level that takes
-    the cumulative side list) -- while the first launches of the later levels pass them by on the engine's stream
-    (engine.cpp, enqueue: the long pairs' chain).  Same kernels and geometries per pair either way: 1200 pairs (12 problems,
-    plane and layered, short and long ones, x 100) must come out BIT-identical with PHOVO_GN_OVERLAP=0 (everything on
-    one stream) -- states, iteration counts, valid pixels, gradient norms -- and equal to the oracle's."""
-    ncfg = native.read_config_file(os.path.join(CFG_DIR, yml))
-    nl = ncfg.num_levels
-    _, ocfg = _cfgs(nl, list(ncfg.max_num_iterations[:nl]), list(ncfg.min_gradient_norm[:nl]))
-    probs = [synthetic.make_pair(400 + i, 640, 480, holes=0.02, trans=(0.01, 0.03, 0.06)[i % 3], rot=(0.004, 0.012, 0.02)[i % 3])
-             for i in range(8)]
-    probs += [synthetic.make_pair(410 + i, 640, 480, scene="layered", trans=(0.03, 0.07)[i % 2], rot=0.01) for i in range(4)]
-    expect = [_oracle_with_counts(ocfg, p) for p in probs]
-    assert max(max(e[1]) for e in expect) > 4, "no pair exceeds the iteration cap: nothing is handed over"
-    src = [2 * (k % 12) for k in range(1200)]
-    tgt = [s + 1 for s in src]
-    out = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("PHOVO_GN_OVERLAP", mode)
-        with odometry.AlignmentEngine() as eng:
-            eng.set_config(ncfg)
-            eng.set_batch_invariant(True)
-            eng.set_intrinsic_matrix(probs[0]["K"])
-            _upload_pairs(eng, probs, 640, 480)
-            a = eng.align_pairs(src, tgt, want_reports=True)
-            b = eng.align_pairs(src, tgt, want_reports=True)          # and again: lists, marks and queue heads start clean
-            total_ms, level_ms = eng.last_align_ms()
-        assert np.array_equal(a[0], b[0])
-        out[mode] = (a, total_ms, level_ms)
-    (s1, r1), t1, lv1 = out["1"]
-    (s0, r0), t0, lv0 = out["0"]
-    assert np.array_equal(s1, s0)
-    for x, y in zip(r1, r0):
-        assert list(x.iterations[:nl]) == list(y.iterations[:nl]) and x.flags == y.flags
-        assert list(x.valid_pixels[:nl]) == list(y.valid_pixels[:nl]) and x.gradient_norm == y.gradient_norm
-    for k in range(1200):
-        es, eits, ev, _ = expect[k % 12]
-        assert list(r1[k].iterations[:nl]) == eits, (k, list(r1[k].iterations[:nl]), eits)
-        assert se3.state_distance(s1[k], es) < POSE_TOL
-        assert list(r1[k].valid_pixels[:nl]) == ev
-    # on one stream the level spans add up to the whole; overlapped they exceed it
-    assert abs(sum(lv0) - t0) < 0.05 * t0 + 0.05
-    print(f"{yml}: one stream {t0:.3f} ms (levels {[round(v, 3) for v in lv0[:nl]]}), overlapped {t1:.3f} ms "
-          f"(level spans {[round(v, 3) for v in lv1[:nl]]})")
-
-
-# ---------------------------------------------------------------------------------------------
-# visualizeIterations, headless
-# ---------------------------------------------------------------------------------------------
 def test_visualize_iterations_writes_the_reference_difference_images(tmp_path, monkeypatch):
     """`visualizeIterations: 1` (config_only_level_0_analytic.yml ships it): the reference shows |I1 - warped source| after
     every iteration that does not end the level (...Analytic.h:515-517,359-362,551-557).  With PHOVO_VISUALIZE_DIR set the

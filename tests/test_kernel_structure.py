@@ -26,9 +26,9 @@ CSRC = os.path.join(ROOT, "photoconsistency-visual-odometry_amd", "csrc")
 def kernels():
     subprocess.run(["make", "-s", "-C", CSRC, "isa"], check=True, capture_output=True)
     out = {}
-    for name, least in (("gn_kernels.s", 15), ("gn_slide_kernel.s", 3)):
+    for name, least in (("gn_kernels.s", 18), ("gn_slide_kernel.s", 3)):
         lines = open(os.path.join(CSRC, "build", name)).read().split("\n")
-        starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN9phovo_hip.*gn_level_kernel.*:", l)]
+        starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN9phovo_hip.*gn_(level|fused)_kernel.*:", l)]
         assert len(starts) >= least, f"{name}: expected every storage x variant instantiation of the level kernels"
         for a in starts:
             b = next(i for i in range(a, len(lines)) if "s_endpgm" in lines[i])
@@ -48,12 +48,6 @@ def test_work_loop_head_is_the_barrier(kernels):
     branches or narrows the exec mask may come first (register spill moves and waits may)."""
     for name, body in kernels.items():
         heads = [i for i, l in enumerate(body) if "This Loop Header: Depth=1" in l]
-        # gn_level_kernel's draw can pass pairs by that are marked as another launch's (GNLevelArgs::skip_marks, levels that
-        # overlap): thread 0's FIRST draw is then a small loop of its own IN FRONT of the work loop (no barrier inside: only
-        # thread 0 is in it, and the queue heads only grow, so it ends); the draws inside the work loop are inner loops.
-        if len(heads) == 2 and "gn_level_kernelI" in name:
-            assert not any(l.strip() == "s_barrier" for l in body[heads[0]:heads[1]]), f"{name}: barrier inside the draw loop"
-            heads = heads[1:]
         assert len(heads) == 1, f"{name}: expected exactly one outermost loop (the work queue), found {len(heads)}"
         if "gn_level_kernelILi64E" in name:
             # one wave per workgroup: the compiler drops every workgroup barrier (a wave is in step with itself and its LDS
@@ -104,16 +98,15 @@ def test_two_draws_from_the_queue(kernels):
     for name, body in kernels.items():
         n = sum("global_atomic_add" in l for l in body)
         # two draw sites (before the loop, in the write-back block), each with ONE add in draw_pair (the queue heads sit a
-        # cache line apart; a single queue is queue 0 of eight); gn_level_kernel can also take its pairs from a hand-over
-        # list (a second add per site) and draw past pairs that are marked as another launch's (draw_pair once more, inside
-        # that loop: a third) and, like the sliding-window kernel, append to a hand-over list (one add, in the write-back
-        # block) -- and, a pair marked for the first time, to the cumulative side list of the long pairs' chain (one more)
+        # cache line apart; a single queue is queue 0 of eight); gn_level_kernel can also take its pairs from the hand-over
+        # list of the sliding-window kernel (a second add per site), which appends to that list (one add, in its write-back
+        # block)
         if "gn_level_kernel_slide" in name:
-            want = 2 * 1 + 2
-        elif "gn_level_kernel_bilinear" in name:
+            want = 2 * 1 + 1
+        elif "gn_level_kernel_bilinear" in name or "gn_fused_kernel" in name:
             want = 2 * 1
         else:
-            want = 2 * 3 + 2
+            want = 2 * 2
         assert n == want, f"{name}: {n} atomic adds, expected {want}"
 
 

@@ -1,27 +1,31 @@
 #!/bin/bash
 # A/B of two builds of libphovo_hip.so on the GPU box (through gpurun, from the repository root):
-#     bash tools/ab_bench.sh gpurun_out/r3/ab1 <library B>      (e.g. a build of an earlier commit, or one with -DPHOVO_AB_*)
-# Runs bench.py (no CPU legs) in its three diagnostic shapes -- shipped thresholds, fixed iterations, every plane streamed
-# once -- with the in-tree library and with library B, and prints one line per run.
+#     bash tools/ab_bench.sh gpurun_out/r4/ab1 <library B> [shapes...]     (e.g. a build of an earlier commit)
+# Runs bench.py (no CPU legs) with the in-tree library and with library B, interleaved twice, and prints one line per run.
+# shapes: shipped fixed layered cfg3 shipped2048 (default: all)
 set -o pipefail
 OUT=$1
 B=${2:?library B (a second build of libphovo_hip.so) is required}
+shift 2
+SHAPES=${*:-shipped fixed layered cfg3 shipped2048}
 mkdir -p "$OUT"
 run() {   # name, library ("" = in-tree), bench arguments
   local name=$1 lib=$2; shift 2
   if [ -n "$lib" ]; then export PHOVO_HIP_LIBRARY=$(realpath "$lib"); else unset PHOVO_HIP_LIBRARY; fi
   timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-reference-termination "$@" > "$OUT/$name.json" 2> "$OUT/$name.err"
-  python3 tools/benchsum.py "$OUT/$name.json" "$name" || true
+  python3 tools/benchsum.py "$OUT/$name.json" "$name" || tail -3 "$OUT/$name.err"
 }
 for rep in 1 2; do
-run shipped_new.$rep "" --thresholds shipped
-run shipped_old.$rep "$B" --thresholds shipped
-run fixed_new.$rep "" 
-run fixed_old.$rep "$B"
-run once_new.$rep "" --max-iterations 0,0,1,1
-run once_old.$rep "$B" --max-iterations 0,0,1,1
+  for s in $SHAPES; do
+    case $s in
+      shipped)     args="--thresholds shipped" ;;
+      fixed)       args="" ;;
+      layered)     args="--thresholds shipped --scene layered --distinct 128" ;;
+      cfg3)        args="--thresholds shipped --workload cfg3" ;;
+      shipped2048) args="--thresholds shipped --pairs 2048" ;;
+      *) echo "unknown shape $s"; exit 2 ;;
+    esac
+    run ${s}_new.$rep "" $args
+    run ${s}_old.$rep "$B" $args
+  done
 done
-run shipped2048_new "" --thresholds shipped --pairs 2048
-run shipped2048_old "$B" --thresholds shipped --pairs 2048
-run cfg3_shipped_new "" --thresholds shipped --workload cfg3
-run cfg3_shipped_old "$B" --thresholds shipped --workload cfg3
