@@ -70,6 +70,11 @@ def parse():
                     help="fixed (default, the headline): min_gradient_norm = 0, every pair runs max_num_iterations; shipped: "
                          "diagnostic, the yml's own min_gradient_norm in the TIMED region (data-dependent early stop) -- what "
                          "tools/profile_round.sh profiles for the shipped configuration; `value` is then not the headline")
+    ap.add_argument("--pipeline", choices=["auto", "on", "off"], default="auto",
+                    help="two enqueues in flight (phovo_hip.h, Pipelining): step k + 1 is enqueued before step k is waited for. "
+                         "auto = on where a gradient threshold makes a batch end with a few long pairs (--thresholds shipped and "
+                         "the reference_termination leg), off for the fixed-iteration headline, whose per-kernel event spans "
+                         "must not overlap")
     ap.add_argument("--scene", choices=["plane", "layered"], default="plane",
                     help="synthetic scene: the slanted textured plane (default) or the layered desk-like scene with depth "
                          "discontinuities, invalid regions and depth noise (synthetic.py)")
@@ -103,22 +108,40 @@ def probe_zero_copy(eng, n_local, device):
         ZERO_COPY["ok"] = False
 
 
-def run_steps(eng, src, tgt, steps, use_dist, device, n_global):
-    """Runs `steps` steps; returns (wall seconds of this rank, per-level kernel ms summed over the steps)."""
+def run_steps(eng, src, tgt, steps, use_dist, device, n_global, pipelined=False):
+    """Runs `steps` steps; returns (wall seconds of this rank, per-level kernel ms summed over the steps).
+
+    pipelined: step k + 1 is enqueued before step k is waited for (phovo_hip.h, "Pipelining": two enqueues in flight, each on
+    its own stream), so the next batch's kernels fill the CUs that the long pairs at the end of a batch leave idle; the
+    results of every step are still gathered, one step behind.  The per-enqueue event spans then overlap and are not summed
+    into anything: with pipelined=True only the wall time is meaningful."""
     per_level = np.zeros(native.MAX_LEVELS + 1)          # [level spans ..., whole enqueue]
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        eng.enqueue_align(src, tgt)
-        eng.synchronize()
+
+    def finish(ticket):
+        eng.wait(ticket)
         if use_dist:
             if ZERO_COPY["ok"]:               # RCCL: start the collective from the engine's own device buffer
-                local = distributed.device_states_tensor(eng.results_device_ptr(), len(src), device)
+                local = distributed.device_states_tensor(eng.device_states(ticket), len(src), device)
             else:
-                local = eng.fetch_results(len(src))
+                local = eng.fetch(ticket, len(src))
             distributed.gather_states(local, n_global, device=device)
-        total_ms, lv = eng.last_align_ms()
+        total_ms, lv = eng.align_ms(ticket)
         per_level[:native.MAX_LEVELS] += np.array(lv)
-        per_level[native.MAX_LEVELS] += total_ms      # first launch to last: the spans of consecutive levels may overlap
+        per_level[native.MAX_LEVELS] += total_ms      # first launch to last
+
+    t0 = time.perf_counter()
+    pending = None
+    for _ in range(steps):
+        eng.enqueue_align(src, tgt)
+        ticket = eng.last_ticket()
+        if pipelined:
+            if pending is not None:
+                finish(pending)
+            pending = ticket
+        else:
+            finish(ticket)
+    if pending is not None:
+        finish(pending)
     return time.perf_counter() - t0, per_level
 
 
@@ -268,7 +291,15 @@ def main():
             run_steps(eng, src, tgt, 1, False, device, n_global)       # something to compare
         probe_zero_copy(eng, n_local, device)
     barrier()
-    wall, per_level_ms = run_steps(eng, src, tgt, args.steps, use_dist, device, n_global)
+    pipe_main = args.pipeline == "on" or (args.pipeline == "auto" and shipped)
+    serial = None
+    if pipe_main:        # the per-enqueue event spans of a pipelined run overlap: take them from a serial run of the same steps first
+        wall_s, per_level_ms = run_steps(eng, src, tgt, args.steps, use_dist, device, n_global)
+        barrier()
+        serial = dict(value=n_local * world * args.steps / wall_s, ms_per_step=1e3 * wall_s / args.steps)
+        wall, _ = run_steps(eng, src, tgt, args.steps, use_dist, device, n_global, pipelined=True)
+    else:
+        wall, per_level_ms = run_steps(eng, src, tgt, args.steps, use_dist, device, n_global)
     barrier()
     if use_dist:
         tmax = torch.tensor([wall], dtype=torch.float64, device=device)
@@ -346,12 +377,16 @@ def main():
         run_steps(eng, src, tgt, 1, use_dist, device, n_global)
         barrier()
         k2 = max(2, args.steps // 2)
-        wall2, lv2 = run_steps(eng, src, tgt, k2, use_dist, device, n_global)
+        wall2, lv2 = run_steps(eng, src, tgt, k2, use_dist, device, n_global)           # one enqueue at a time: event spans
         barrier()
+        wall2_serial = wall2
+        if args.pipeline != "off":
+            wall2, _ = run_steps(eng, src, tgt, k2, use_dist, device, n_global, pipelined=True)
+            barrier()
         if use_dist:
-            tmax = torch.tensor([wall2], dtype=torch.float64, device=device)
+            tmax = torch.tensor([wall2, wall2_serial], dtype=torch.float64, device=device)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            wall2 = float(tmax.item())
+            wall2, wall2_serial = float(tmax[0].item()), float(tmax[1].item())
         _, reps2 = eng.fetch_results(n_local, want_reports=True)
         it2 = np.array([list(r.iterations[:nl]) for r in reps2])
         hist = {}
@@ -360,6 +395,7 @@ def main():
                 vals, counts = np.unique(it2[:, l], return_counts=True)
                 hist[f"level_{l}"] = {int(v): int(c) for v, c in zip(vals, counts)}
         ref_term = dict(value=n_global * k2 / wall2, unit="alignments/s", steps=k2,
+                        pipelined=args.pipeline != "off", one_enqueue_at_a_time=n_global * k2 / wall2_serial,
                         mean_iterations_per_level=[float(x) for x in it2.mean(axis=0)],
                         max_iterations_per_level=[int(x) for x in it2.max(axis=0)],
                         avg_launch_ms_per_level=[float(x) / k2 for x in lv2[:nl]],
@@ -512,6 +548,8 @@ def main():
                                + " all_gather of states",
                 "all_gather_from_device_buffer": ZERO_COPY["ok"],
             },
+            "pipelined": bool(pipe_main),
+            "one_enqueue_at_a_time": serial,      # pipelined runs only: the same steps, each waited for before the next
             "iterations_per_pair": [float(x) for x in iters.mean(axis=0)],
             "nonfinite_pairs": nonfinite,
             "window_fallback_pairs": window_fallback,

@@ -298,9 +298,10 @@ int phovo_engine_align_pairs(phovo_engine *e, int n_pairs,
                              const int *source_frames, const int *target_frames,
                              const double *init_states, double *out_states,
                              phovo_pair_report *reports);
-/* Split form: enqueue on the engine's stream without waiting, then wait, then fetch.  The argument arrays are
- * copied before the call returns.  (Levels that run in the wide form synchronise the stream every 8 iterations
- * to look at the "done" words, so for them the call returns when the level has finished.) */
+/* Split form: enqueue without waiting, then wait, then fetch.  The argument arrays are copied before the call
+ * returns.  (Levels that run in the wide form synchronise the stream every 8 iterations to look at the "done" words,
+ * so for them the call returns when the level has finished.)  phovo_engine_synchronize waits for everything the engine
+ * has in flight; fetch_results / results_device_ptr / last_align_ms / last_launches speak of the LAST enqueue. */
 int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs,
                                const int *source_frames, const int *target_frames,
                                const double *init_states);
@@ -310,8 +311,29 @@ int phovo_engine_fetch_results(phovo_engine *e, int n_pairs, double *out_states,
 /* Device pointer to the n_pairs x 6 fp64 result of the last enqueue (for an RCCL gather). */
 int phovo_engine_results_device_ptr(phovo_engine *e, void **states);
 
-/* Device time (ms, HIP events on the engine's stream) of the last enqueue: total over the
- * per-level launches, and per level (0 for levels that were not launched). */
+/* Pipelining.  Pairs are independent, and with data-dependent termination a batch ends with a few long pairs on an
+ * otherwise idle chip.  The engine therefore keeps PHOVO_ENQUEUE_DEPTH enqueues in flight, each with its own stream, pair
+ * buffers and pinned mirrors: phovo_engine_enqueue_align returns at once, and the kernels of enqueue k + 1 fill the CUs
+ * that the tail of enqueue k leaves free.  Every enqueue gets a ticket (1, 2, ...; phovo_engine_last_ticket right after the
+ * call); a ticket stays valid -- its results fetchable -- until PHOVO_ENQUEUE_DEPTH later enqueues have been issued.  The
+ * slot an enqueue takes is waited for inside phovo_engine_enqueue_align, so a caller that never looks at tickets sees the
+ * behaviour of a single stream, except that two consecutive enqueues may overlap on the device.  Uploads, plane writes
+ * and configuration changes wait for every enqueue in flight before they touch device memory.
+ *     for (k = 0; k < steps; k++) {
+ *       phovo_engine_enqueue_align(e, n, src[k], tgt[k], NULL);  t[k] = phovo_engine_last_ticket(e);
+ *       if (k > 0) phovo_engine_fetch(e, t[k - 1], n, states[k - 1], NULL);      // waits for enqueue k - 1 only
+ *     }
+ *     phovo_engine_fetch(e, t[steps - 1], n, states[steps - 1], NULL);
+ * Results do not depend on what else is in flight (same kernels, same arithmetic per pair). */
+#define PHOVO_ENQUEUE_DEPTH 2
+int phovo_engine_last_ticket(const phovo_engine *e);                       /* 0 before the first enqueue */
+int phovo_engine_wait(phovo_engine *e, int ticket);                        /* host wait for that enqueue alone */
+int phovo_engine_fetch(phovo_engine *e, int ticket, int n_pairs, double *out_states, phovo_pair_report *reports);
+int phovo_engine_device_states(phovo_engine *e, int ticket, void **states);    /* n_pairs x 6 fp64 in HBM */
+int phovo_engine_align_ms(const phovo_engine *e, int ticket, double *total_ms, double level_ms[PHOVO_MAX_LEVELS]);
+
+/* Device time (ms, HIP events on the enqueue's stream) of the last enqueue: first launch to last, and per level (0 for
+ * levels that were not launched; a fused launch is reported at the coarsest level it covers). */
 int phovo_engine_last_align_ms(const phovo_engine *e, double *total_ms,
                                double level_ms[PHOVO_MAX_LEVELS]);
 /* What the last enqueue launched, in launch order: one record per kernel launch (the wide form: per level). */

@@ -54,16 +54,46 @@ struct LevelPool {
 
 using namespace phovo_hip;
 
-struct phovo_engine {
-  int device = 0;
+// Everything ONE enqueue owns: its stream, its pair data, its scratch and its timing events.  The engine keeps
+// PHOVO_ENQUEUE_DEPTH of them and uses them in turn, so that enqueue k + 1 can be issued -- and its kernels can start filling
+// the CUs that enqueue k's last, long pairs leave idle -- before enqueue k has finished (phovo_hip.h, "Pipelining").
+struct AlignSlot {
   hipStream_t stream = nullptr;
-  hipStream_t copy_stream = nullptr;           // batched uploads: host-to-device copies of chunk i+1 run beside the pyramid kernels of chunk i
-  hipEvent_t ev_copied[2] = {}, ev_built[2] = {};     // per staging half
   hipEvent_t ev_total_start = nullptr, ev_total_stop = nullptr;
   hipEvent_t ev_start[PHOVO_MAX_LEVELS] = {};
   hipEvent_t ev_stop[PHOVO_MAX_LEVELS] = {};
   bool level_launched[PHOVO_MAX_LEVELS] = {};
   bool have_timing = false;
+  int ticket = 0;                              // the enqueue this slot holds (0: none yet)
+  int last_pairs = 0;
+  // Per-launch pair data in ONE device allocation, laid out for the pairs of the enqueue as
+  //   [src int32 | tgt int32 | states fp64 x6 | reports | work-queue heads | hand-over lists]
+  // so that an enqueue is one host-to-device copy (src, tgt, initial states, from the pinned mirror h_up) and one
+  // memset (reports + heads + lists), and a fetch is one device-to-host copy (states + reports, into the pinned h_down).
+  int pair_capacity = 0;
+  unsigned char *d_pairs = nullptr;
+  unsigned char *h_up = nullptr, *h_down = nullptr;      // pinned
+  int *d_src = nullptr, *d_tgt = nullptr;                // views into d_pairs for the enqueue
+  double *d_states = nullptr;
+  phovo_pair_report *d_reports = nullptr;
+  int *d_work_counters = nullptr;              // [2][PHOVO_MAX_LEVELS][QUEUES_PER_LEVEL x QUEUE_HEAD_STRIDE] work-queue heads of the level launches (view into d_pairs)
+  int *d_handover = nullptr;                   // [PHOVO_MAX_LEVELS][pairs + 2] hand-over lists: sliding-window kernel -> exact kernel (view into d_pairs)
+  int *d_owner = nullptr;                      // owner maps in HBM (levels whose map exceeds LDS; the wide form)
+  size_t owner_capacity = 0;
+  bool owner_tagged = false;                   // d_owner holds tagged entries of the persistent kernel, not the -1 the wide form expects
+  void *d_wide_ws = nullptr;                   // workspace of the wide (many-workgroups-per-pair) level form
+  size_t wide_ws_capacity = 0;
+  std::vector<int> h_wide_done;
+  std::vector<phovo_launch_record> launches;   // what the enqueue launched, in order (phovo_engine_last_launches)
+};
+
+struct phovo_engine {
+  int device = 0;
+  hipStream_t stream = nullptr;                // uploads, pyramid producers, plane access
+  hipStream_t copy_stream = nullptr;           // batched uploads: host-to-device copies of chunk i+1 run beside the pyramid kernels of chunk i
+  hipEvent_t ev_copied[2] = {}, ev_built[2] = {};     // per staging half
+  AlignSlot slots[PHOVO_ENQUEUE_DEPTH];
+  int ticket = 0;                              // tickets handed out so far; enqueue t lives in slots[t % PHOVO_ENQUEUE_DEPTH]
 
   phovo_config cfg{};
   phovo_extensions ext{};                      // plane storage, Huber deltas: all off by default
@@ -86,31 +116,11 @@ struct phovo_engine {
   double *d_blur_kernel = nullptr;             // [levels][max ksize]
   int blur_kernel_stride = 0;
 
-  // Per-launch pair data in ONE device allocation, laid out for the pairs of the current enqueue as
-  //   [src int32 | tgt int32 | states fp64 x6 | reports | work-queue heads]
-  // so that an enqueue is one host-to-device copy (src, tgt, initial states, from the pinned mirror h_up) and one
-  // memset (reports + heads), and a fetch is one device-to-host copy (states + reports, into the pinned h_down).
-  int pair_capacity = 0;
-  unsigned char *d_pairs = nullptr;
-  unsigned char *h_up = nullptr, *h_down = nullptr;      // pinned
-  int *d_src = nullptr, *d_tgt = nullptr;                // views into d_pairs for the current enqueue
-  double *d_states = nullptr;
-  phovo_pair_report *d_reports = nullptr;
-  int *d_owner = nullptr;
-  size_t owner_capacity = 0;
-  bool owner_tagged = false;                   // d_owner holds tagged entries of the persistent kernel, not the -1 the wide form expects
-  int *d_work_counters = nullptr;              // [2][PHOVO_MAX_LEVELS][QUEUES_PER_LEVEL x QUEUE_HEAD_STRIDE] work-queue heads of the level launches (view into d_pairs)
-  int *d_handover = nullptr;                   // [PHOVO_MAX_LEVELS][pairs + 2] hand-over lists: sliding-window kernel -> exact kernel (view into d_pairs)
   int slide_policy = 0;                        // 0 automatic (where the owner map exceeds LDS), -1 never
   int fusion = PHOVO_FUSION_AUTO;              // consecutive levels in one launch (phovo_engine_set_level_fusion)
-  std::vector<phovo_launch_record> launches;   // what the last enqueue launched, in order (phovo_engine_last_launches)
   int cu_count = 256;
-  void *d_wide_ws = nullptr;                   // workspace of the wide (many-workgroups-per-pair) level form
-  size_t wide_ws_capacity = 0;
-  std::vector<int> h_wide_done;
   int wide_policy = 0;                         // 0 auto, 1 always (where possible), -1 never
   bool batch_invariant = false;                // every batch takes the same kernels and geometries (phovo_engine_set_batch_invariant)
-  int last_pairs = 0;
 };
 
 namespace {
@@ -135,17 +145,34 @@ void free_pool(phovo_engine *e)
   e->n_frames = 0; e->width = 0; e->height = 0;
 }
 
-void free_pairs(phovo_engine *e)
+void free_pairs(AlignSlot &s)
 {
-  if (e->d_pairs) (void)hipFree(e->d_pairs);
-  if (e->h_up) (void)hipHostFree(e->h_up);
-  if (e->h_down) (void)hipHostFree(e->h_down);
-  e->d_pairs = nullptr; e->h_up = e->h_down = nullptr; e->d_work_counters = nullptr; e->d_handover = nullptr;
-  if (e->d_owner) (void)hipFree(e->d_owner);
-  if (e->d_wide_ws) (void)hipFree(e->d_wide_ws);
-  e->d_wide_ws = nullptr; e->wide_ws_capacity = 0;
-  e->d_src = e->d_tgt = nullptr; e->d_states = nullptr; e->d_reports = nullptr; e->d_owner = nullptr;
-  e->pair_capacity = 0; e->owner_capacity = 0;
+  if (s.d_pairs) (void)hipFree(s.d_pairs);
+  if (s.h_up) (void)hipHostFree(s.h_up);
+  if (s.h_down) (void)hipHostFree(s.h_down);
+  s.d_pairs = nullptr; s.h_up = s.h_down = nullptr; s.d_work_counters = nullptr; s.d_handover = nullptr;
+  s.d_src = s.d_tgt = nullptr; s.d_states = nullptr; s.d_reports = nullptr;
+  s.pair_capacity = 0;
+}
+
+void free_slot(AlignSlot &s)
+{
+  free_pairs(s);
+  if (s.d_owner) (void)hipFree(s.d_owner);
+  if (s.d_wide_ws) (void)hipFree(s.d_wide_ws);
+  s.d_owner = nullptr; s.owner_capacity = 0; s.d_wide_ws = nullptr; s.wide_ws_capacity = 0;
+}
+
+// Every enqueue in flight has finished when this returns (host wait).  Called by whatever changes device state that a
+// running alignment reads: uploads, plane writes, pool and configuration changes.
+hipError_t quiesce(phovo_engine *e)
+{
+  for (AlignSlot &s : e->slots) {
+    if (!s.stream) continue;
+    const hipError_t he = hipStreamSynchronize(s.stream);
+    if (he != hipSuccess) return he;
+  }
+  return hipSuccess;
 }
 
 int validate_config(const phovo_config *c)
@@ -201,21 +228,15 @@ PairLayout pair_layout(int n_pairs)
   return l;
 }
 
-int ensure_pairs(phovo_engine *e, int n_pairs)
+int ensure_pairs(AlignSlot &s, int n_pairs)
 {
-  if (n_pairs <= e->pair_capacity) return PHOVO_OK;
-  const size_t keep_owner = e->owner_capacity, keep_ws_cap = e->wide_ws_capacity;
-  int *keep = e->d_owner;
-  void *keep_ws = e->d_wide_ws;
-  e->d_owner = nullptr; e->d_wide_ws = nullptr;
-  free_pairs(e);
-  e->d_owner = keep; e->owner_capacity = keep_owner;
-  e->d_wide_ws = keep_ws; e->wide_ws_capacity = keep_ws_cap;
+  if (n_pairs <= s.pair_capacity) return PHOVO_OK;
+  free_pairs(s);
   const PairLayout cap = pair_layout(n_pairs);
-  PHOVO_HIP_CHECK(hipMalloc(&e->d_pairs, cap.total));
-  PHOVO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&e->h_up), cap.reports, hipHostMallocDefault));
-  PHOVO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&e->h_down), cap.heads - cap.states, hipHostMallocDefault));
-  e->pair_capacity = n_pairs;
+  PHOVO_HIP_CHECK(hipMalloc(&s.d_pairs, cap.total));
+  PHOVO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&s.h_up), cap.reports, hipHostMallocDefault));
+  PHOVO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&s.h_down), cap.heads - cap.states, hipHostMallocDefault));
+  s.pair_capacity = n_pairs;
   return PHOVO_OK;
 }
 
@@ -432,16 +453,17 @@ int phovo_engine_create(int device, phovo_engine **out)
   phovo_extensions_default(&e->ext);
   hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
   if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking);
-  if (he == hipSuccess) he = hipEventCreate(&e->ev_total_start);
-  if (he == hipSuccess) he = hipEventCreate(&e->ev_total_stop);
   for (int i = 0; i < 2 && he == hipSuccess; i++) {
     he = hipEventCreateWithFlags(&e->ev_copied[i], hipEventDisableTiming);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_built[i], hipEventDisableTiming);
   }
-  if (he == hipSuccess) {
+  for (AlignSlot &s : e->slots) {
+    if (he == hipSuccess) he = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+    if (he == hipSuccess) he = hipEventCreate(&s.ev_total_start);
+    if (he == hipSuccess) he = hipEventCreate(&s.ev_total_stop);
     for (int l = 0; l < PHOVO_MAX_LEVELS && he == hipSuccess; l++) {
-      he = hipEventCreate(&e->ev_start[l]);
-      if (he == hipSuccess) he = hipEventCreate(&e->ev_stop[l]);
+      he = hipEventCreate(&s.ev_start[l]);
+      if (he == hipSuccess) he = hipEventCreate(&s.ev_stop[l]);
     }
   }
   if (he == hipSuccess) he = gn_prepare_kernels();
@@ -464,18 +486,22 @@ int phovo_engine_destroy(phovo_engine *e)
   (void)hipSetDevice(e->device);
   if (e->copy_stream) (void)hipStreamSynchronize(e->copy_stream);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
+  (void)quiesce(e);
   free_pool(e);
-  free_pairs(e);
-  for (int l = 0; l < PHOVO_MAX_LEVELS; l++) {
-    if (e->ev_start[l]) (void)hipEventDestroy(e->ev_start[l]);
-    if (e->ev_stop[l]) (void)hipEventDestroy(e->ev_stop[l]);
+  for (AlignSlot &s : e->slots) {
+    free_slot(s);
+    for (int l = 0; l < PHOVO_MAX_LEVELS; l++) {
+      if (s.ev_start[l]) (void)hipEventDestroy(s.ev_start[l]);
+      if (s.ev_stop[l]) (void)hipEventDestroy(s.ev_stop[l]);
+    }
+    if (s.ev_total_start) (void)hipEventDestroy(s.ev_total_start);
+    if (s.ev_total_stop) (void)hipEventDestroy(s.ev_total_stop);
+    if (s.stream) (void)hipStreamDestroy(s.stream);
   }
   for (int i = 0; i < 2; i++) {
     if (e->ev_copied[i]) (void)hipEventDestroy(e->ev_copied[i]);
     if (e->ev_built[i]) (void)hipEventDestroy(e->ev_built[i]);
   }
-  if (e->ev_total_start) (void)hipEventDestroy(e->ev_total_start);
-  if (e->ev_total_stop) (void)hipEventDestroy(e->ev_total_stop);
   if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -498,6 +524,7 @@ int phovo_engine_set_config(phovo_engine *e, const phovo_config *cfg)
   }
   (void)hipSetDevice(e->device);
   (void)hipStreamSynchronize(e->stream);
+  (void)quiesce(e);
   if (!keep) free_pool(e);
   e->cfg = *cfg;
   return PHOVO_OK;
@@ -529,6 +556,7 @@ int phovo_engine_set_extensions(phovo_engine *e, const phovo_extensions *ext)
   if (ext->plane_storage != e->ext.plane_storage) {      // the pool layout changes
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
+  (void)quiesce(e);
     free_pool(e);
   }
   e->ext = *ext;
@@ -609,6 +637,7 @@ int phovo_engine_set_build_all_levels(phovo_engine *e, int on)
   if ((on != 0) != e->build_all) {
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
+  (void)quiesce(e);
     free_pool(e);
   }
   e->build_all = on != 0;
@@ -659,6 +688,7 @@ int phovo_engine_reserve_frames(phovo_engine *e, int n_frames, int width, int he
   if (n_frames < 1 || width < 1 || height < 1) return fail(PHOVO_E_INVALID_ARGUMENT, "reserve_frames: sizes must be positive");
   PHOVO_HIP_CHECK(hipSetDevice(e->device));
   PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
+  PHOVO_HIP_CHECK(quiesce(e));
   free_pool(e);
   size_t max_n = 0;
   int max_ks = 0;
@@ -777,6 +807,7 @@ static int upload_batch(phovo_engine *e, int first_frame, int count, int roles,
   if (!(roles & PHOVO_ROLE_SOURCE)) kind = DEPTH_NONE;
   if (count == 0) return PHOVO_OK;
   PHOVO_HIP_CHECK(hipSetDevice(e->device));
+  PHOVO_HIP_CHECK(quiesce(e));                 // (an alignment in flight may be reading the frames about to be replaced)
   const int chunk_cap = count < STAGE_CHUNK ? count : STAGE_CHUNK;
   // Two staging halves: while the pyramid kernels of chunk i read one half on the engine's stream, chunk i + 1 is copied
   // into the other on the copy stream (events order each half: copied -> built -> copied again).
@@ -790,6 +821,7 @@ static int upload_batch(phovo_engine *e, int first_frame, int count, int roles,
   auto drain = [&](int status) {
     (void)hipStreamSynchronize(e->copy_stream);
     (void)hipStreamSynchronize(e->stream);
+  (void)quiesce(e);
     return status;
   };
 #define PHOVO_UPLOAD_CHECK(expr)                                                                              \
@@ -874,6 +906,7 @@ int phovo_engine_set_level_planes(phovo_engine *e, int frame, int level,
   const int st = plane_access_check(e, frame, level);
   if (st != PHOVO_OK) return st;
   PHOVO_HIP_CHECK(hipSetDevice(e->device));
+  PHOVO_HIP_CHECK(quiesce(e));
   const LevelPool &lv = e->levels[level];
   unsigned char *base = lv.planes + (size_t)frame * lv.frame_bytes;
   const double *srcs[4] = {intensity, depth, grad_x, grad_y};
@@ -927,12 +960,21 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
     if (source_frames[i] < 0 || source_frames[i] >= e->n_frames || target_frames[i] < 0 || target_frames[i] >= e->n_frames)
       return fail(PHOVO_E_INVALID_ARGUMENT, "align: frame index out of range");
   }
-  e->last_pairs = n_pairs;
-  e->have_timing = false;
-  for (bool &b : e->level_launched) b = false;
-  if (n_pairs == 0) return PHOVO_OK;
   PHOVO_HIP_CHECK(hipSetDevice(e->device));
-  int st = ensure_pairs(e, n_pairs);
+  // The slot this enqueue takes: the one used least recently.  Its previous enqueue (ticket - PHOVO_ENQUEUE_DEPTH) must
+  // have finished -- its pinned mirror and pair data are about to be rewritten -- but the enqueue before this one may
+  // still be running: it lives in the other slot, on the other stream.
+  const int ticket = ++e->ticket;
+  AlignSlot &s = e->slots[ticket % PHOVO_ENQUEUE_DEPTH];
+  PHOVO_HIP_CHECK(hipStreamSynchronize(s.stream));
+  s.ticket = ticket;
+  s.last_pairs = n_pairs;
+  s.have_timing = false;
+  s.launches.clear();
+  for (bool &b : s.level_launched) b = false;
+  if (n_pairs == 0) return PHOVO_OK;
+  // planes written on the engine's own stream so far (uploads return synchronised; plane setters too): nothing to order
+  int st = ensure_pairs(s, n_pairs);
   if (st != PHOVO_OK) return st;
 
   // every active level must be launchable before anything is enqueued
@@ -953,48 +995,45 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
       if (need > owner_need) owner_need = need;
     }
   }
-  if (owner_need > e->owner_capacity) {
-    if (e->d_owner) { PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream)); (void)hipFree(e->d_owner); e->d_owner = nullptr; e->owner_capacity = 0; }
-    PHOVO_HIP_CHECK(hipMalloc(&e->d_owner, sizeof(int) * owner_need));
-    e->owner_capacity = owner_need;
-    e->owner_tagged = false;
+  if (owner_need > s.owner_capacity) {
+    if (s.d_owner) { PHOVO_HIP_CHECK(hipStreamSynchronize(s.stream)); (void)hipFree(s.d_owner); s.d_owner = nullptr; s.owner_capacity = 0; }
+    PHOVO_HIP_CHECK(hipMalloc(&s.d_owner, sizeof(int) * owner_need));
+    s.owner_capacity = owner_need;
+    s.owner_tagged = false;
     // -1 everywhere once: the wide form restores -1 after every iteration, the persistent kernel wipes per pair
-    PHOVO_HIP_CHECK(fill_i32(e->d_owner, owner_need, -1, e->stream));
+    PHOVO_HIP_CHECK(fill_i32(s.d_owner, owner_need, -1, s.stream));
   }
 
-  if (wide_need > e->wide_ws_capacity) {
-    if (e->d_wide_ws) { PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream)); (void)hipFree(e->d_wide_ws); e->d_wide_ws = nullptr; e->wide_ws_capacity = 0; }
-    PHOVO_HIP_CHECK(hipMalloc(&e->d_wide_ws, wide_need));
-    e->wide_ws_capacity = wide_need;
+  if (wide_need > s.wide_ws_capacity) {
+    if (s.d_wide_ws) { PHOVO_HIP_CHECK(hipStreamSynchronize(s.stream)); (void)hipFree(s.d_wide_ws); s.d_wide_ws = nullptr; s.wide_ws_capacity = 0; }
+    PHOVO_HIP_CHECK(hipMalloc(&s.d_wide_ws, wide_need));
+    s.wide_ws_capacity = wide_need;
   }
-  if (wide_need) e->h_wide_done.resize((size_t)n_pairs * 4);
-  // The caller may reuse its arrays as soon as this returns and the copies below are asynchronous: keep
-  // engine-owned copies alive until the next enqueue (the previous ones are no longer in flight: the stream
-  // is in order and their copies precede everything enqueued since).
-  PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
+  if (wide_need) s.h_wide_done.resize((size_t)n_pairs * 4);
+  // The caller may reuse its arrays as soon as this returns and the copies below are asynchronous: the slot's pinned
+  // mirror keeps them alive until the slot is used again (synchronised above).
   const PairLayout pl = pair_layout(n_pairs);
-  e->d_src = reinterpret_cast<int *>(e->d_pairs + pl.src);
-  e->d_tgt = reinterpret_cast<int *>(e->d_pairs + pl.tgt);
-  e->d_states = reinterpret_cast<double *>(e->d_pairs + pl.states);
-  e->d_reports = reinterpret_cast<phovo_pair_report *>(e->d_pairs + pl.reports);
-  e->d_work_counters = reinterpret_cast<int *>(e->d_pairs + pl.heads);
-  e->d_handover = reinterpret_cast<int *>(e->d_pairs + pl.handover);
-  std::memset(e->h_up, 0, pl.reports);
-  std::memcpy(e->h_up + pl.src, source_frames, sizeof(int) * (size_t)n_pairs);
-  std::memcpy(e->h_up + pl.tgt, target_frames, sizeof(int) * (size_t)n_pairs);
+  s.d_src = reinterpret_cast<int *>(s.d_pairs + pl.src);
+  s.d_tgt = reinterpret_cast<int *>(s.d_pairs + pl.tgt);
+  s.d_states = reinterpret_cast<double *>(s.d_pairs + pl.states);
+  s.d_reports = reinterpret_cast<phovo_pair_report *>(s.d_pairs + pl.reports);
+  s.d_work_counters = reinterpret_cast<int *>(s.d_pairs + pl.heads);
+  s.d_handover = reinterpret_cast<int *>(s.d_pairs + pl.handover);
+  std::memset(s.h_up, 0, pl.reports);
+  std::memcpy(s.h_up + pl.src, source_frames, sizeof(int) * (size_t)n_pairs);
+  std::memcpy(s.h_up + pl.tgt, target_frames, sizeof(int) * (size_t)n_pairs);
   if (init_states)                                                                   // SetInitialStateVector  :494
-    std::memcpy(e->h_up + pl.states, init_states, sizeof(double) * 6 * (size_t)n_pairs);
+    std::memcpy(s.h_up + pl.states, init_states, sizeof(double) * 6 * (size_t)n_pairs);
   // one copy in (pair list + initial states, zeros without them), one memset (reports + the work-queue heads of all levels)
-  PHOVO_HIP_CHECK(hipMemcpyAsync(e->d_pairs, e->h_up, pl.reports, hipMemcpyHostToDevice, e->stream));
-  PHOVO_HIP_CHECK(hipMemsetAsync(e->d_pairs + pl.reports, 0, pl.total - pl.reports, e->stream));
-  PHOVO_HIP_CHECK(hipEventRecord(e->ev_total_start, e->stream));
+  PHOVO_HIP_CHECK(hipMemcpyAsync(s.d_pairs, s.h_up, pl.reports, hipMemcpyHostToDevice, s.stream));
+  PHOVO_HIP_CHECK(hipMemsetAsync(s.d_pairs + pl.reports, 0, pl.total - pl.reports, s.stream));
+  PHOVO_HIP_CHECK(hipEventRecord(s.ev_total_start, s.stream));
 
   const PairLayout lay = pair_layout(n_pairs);
-  e->launches.clear();
   auto record = [&](int first, int last, int kind, int threads, int lds, int wgs) {
     phovo_launch_record r{};
     r.level_first = first; r.level_last = last; r.kind = kind; r.threads = threads; r.lds_bytes = lds; r.workgroups = wgs;
-    e->launches.push_back(r);
+    s.launches.push_back(r);
   };
   auto persistent_grid = [&](int wgs_per_cu) { const int slots = e->cu_count * wgs_per_cu; return n_pairs < slots ? n_pairs : slots; };
   auto level_args = [&](int l) {
@@ -1014,11 +1053,11 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
     a.frame_bytes = lv.frame_bytes;
     for (int p = 0; p < PLANES_PER_FRAME; p++) a.plane_off[p] = lv.plane_off[p];
     a.huber_delta = e->ext.huber_delta[l];
-    a.src = e->d_src; a.tgt = e->d_tgt;
-    a.states = e->d_states; a.reports = e->d_reports;
-    a.g_owner = e->d_owner;
+    a.src = s.d_src; a.tgt = s.d_tgt;
+    a.states = s.d_states; a.reports = s.d_reports;
+    a.g_owner = s.d_owner;
     a.n_pairs = n_pairs;
-    a.work_counter = e->d_work_counters + l * QUEUE_HEADS_INTS;
+    a.work_counter = s.d_work_counters + l * QUEUE_HEADS_INTS;
     // one queue per XCD once there are enough pairs to keep every XCD's share of the grid busy
     a.n_queues = (!tuning_switch("PHOVO_QUEUE_SINGLE") && n_pairs >= 8 * 64) ? QUEUES_PER_LEVEL : 1;
     return a;
@@ -1038,7 +1077,7 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
     if (e->cfg.max_num_iterations[l] <= 0) continue;                                 // :526 (nothing observable happens)
     const LevelPool &lv = e->levels[l];
     GNLevelArgs a = level_args(l);
-    PHOVO_HIP_CHECK(hipEventRecord(e->ev_start[l], e->stream));
+    PHOVO_HIP_CHECK(hipEventRecord(s.ev_start[l], s.stream));
 
     // Data-dependent termination (a gradient threshold on any of them): the run of consecutive fusable levels that starts
     // here goes out as ONE persistent launch in which every pair flows through those levels inside the workgroup that drew
@@ -1062,10 +1101,10 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
           f.lv[i] = level_args(run[i]);
           if (f.lv[i].n > f.n_max) f.n_max = f.lv[i].n;
         }
-        PHOVO_HIP_CHECK(gn_launch_fused(f, e->ext.plane_storage, e->cu_count, e->stream));
+        PHOVO_HIP_CHECK(gn_launch_fused(f, e->ext.plane_storage, e->cu_count, s.stream));
         record(l, run[n_run - 1], PHOVO_LAUNCH_FUSED, 512, gn_fused_lds_bytes(f.n_max), persistent_grid(2));
-        PHOVO_HIP_CHECK(hipEventRecord(e->ev_stop[l], e->stream));
-        e->level_launched[l] = true;
+        PHOVO_HIP_CHECK(hipEventRecord(s.ev_stop[l], s.stream));
+        s.level_launched[l] = true;
         l = run[n_run - 1];                        // (the loop's l-- moves on to the level below the run)
         continue;
       }
@@ -1073,62 +1112,75 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
         // the fused geometry, one launch per level: what a fused run is bit-identical to (tests)
         GNLaunchPlan mid{};
         (void)gn_plan_fused_geometry(lv.n, &mid);
-        PHOVO_HIP_CHECK(gn_launch_level(a, mid, e->ext.plane_storage, e->cu_count, e->stream));
+        PHOVO_HIP_CHECK(gn_launch_level(a, mid, e->ext.plane_storage, e->cu_count, s.stream));
         record(l, l, PHOVO_LAUNCH_PERSISTENT, mid.threads, mid.lds_bytes, persistent_grid(mid.wgs_per_cu));
-        PHOVO_HIP_CHECK(hipEventRecord(e->ev_stop[l], e->stream));
-        e->level_launched[l] = true;
+        PHOVO_HIP_CHECK(hipEventRecord(s.ev_stop[l], s.stream));
+        s.level_launched[l] = true;
         continue;
       }
     }
 
     if (e->ext.sampling == PHOVO_SAMPLING_BILINEAR) {
-      PHOVO_HIP_CHECK(gn_launch_level_bilinear(a, e->ext.plane_storage, e->ext.jacobian_corrected != 0, e->cu_count, e->stream));
+      PHOVO_HIP_CHECK(gn_launch_level_bilinear(a, e->ext.plane_storage, e->ext.jacobian_corrected != 0, e->cu_count, s.stream));
       record(l, l, PHOVO_LAUNCH_BILINEAR, 256, 0, persistent_grid(gn_bilinear_wgs_per_cu()));
     } else if (use_wide_level(e, n_pairs, lv.n) && !(e->ext.huber_delta[l] > 0.0)) {
-      if (e->owner_tagged) {            // the wide form starts from -1 everywhere and leaves it so
-        PHOVO_HIP_CHECK(fill_i32(e->d_owner, e->owner_capacity, -1, e->stream));
-        e->owner_tagged = false;
+      if (s.owner_tagged) {            // the wide form starts from -1 everywhere and leaves it so
+        PHOVO_HIP_CHECK(fill_i32(s.d_owner, s.owner_capacity, -1, s.stream));
+        s.owner_tagged = false;
       }
-      PHOVO_HIP_CHECK(gn_run_level_wide(a, n_pairs, e->d_wide_ws, e->h_wide_done.data(), e->stream));
+      PHOVO_HIP_CHECK(gn_run_level_wide(a, n_pairs, s.d_wide_ws, s.h_wide_done.data(), s.stream));
       record(l, l, PHOVO_LAUNCH_WIDE, 256, 0, n_pairs * ((lv.n + 1023) / 1024));
     } else {
       const bool few = few_batch && lv.plan_few_ok && lv.plan_few.owner_in_lds == lv.plan.owner_in_lds;
       const GNLaunchPlan &pl = few ? lv.plan_few : lv.plan;
       a.n_lds = pl.owner_in_lds ? 0 : pl.owner_lds_entries;
-      int *list0 = e->d_handover + (size_t)l * lay.handover_stride;
-      int *heads1 = e->d_work_counters + (PHOVO_MAX_LEVELS + l) * QUEUE_HEADS_INTS;
+      int *list0 = s.d_handover + (size_t)l * lay.handover_stride;
+      int *heads1 = s.d_work_counters + (PHOVO_MAX_LEVELS + l) * QUEUE_HEADS_INTS;
       if (!pl.owner_in_lds && e->slide_policy >= 0) {
         // Owner map too large for LDS: the sliding-window kernel first (owner ring in LDS); pairs whose warp leaves its
         // window are put on the hand-over list and continued, from the iteration they had reached, by the exact kernel
         // right behind it, which draws from that list.
         a.handover_out = list0;
-        PHOVO_HIP_CHECK(gn_launch_level_slide(a, e->ext.plane_storage, e->cu_count, e->stream));
+        PHOVO_HIP_CHECK(gn_launch_level_slide(a, e->ext.plane_storage, e->cu_count, s.stream));
         record(l, l, PHOVO_LAUNCH_SLIDE, 512, (int)gn_slide_lds_bytes(), persistent_grid(1));
         a.handover_out = nullptr; a.handover_in = list0; a.takeover_flag = PHOVO_PAIR_WINDOW_FALLBACK;
         a.work_counter = heads1; a.n_queues = 1;
-        PHOVO_HIP_CHECK(gn_launch_level(a, pl, e->ext.plane_storage, e->cu_count, e->stream));
+        PHOVO_HIP_CHECK(gn_launch_level(a, pl, e->ext.plane_storage, e->cu_count, s.stream));
         record(l, l, PHOVO_LAUNCH_SLIDE_FALLBACK, pl.threads, pl.lds_bytes, persistent_grid(pl.wgs_per_cu));
-        e->owner_tagged = true;                              // tagged entries stay behind (the kernel wipes per pair)
+        s.owner_tagged = true;                              // tagged entries stay behind (the kernel wipes per pair)
       } else {
-        PHOVO_HIP_CHECK(gn_launch_level(a, pl, e->ext.plane_storage, e->cu_count, e->stream));
+        PHOVO_HIP_CHECK(gn_launch_level(a, pl, e->ext.plane_storage, e->cu_count, s.stream));
         record(l, l, PHOVO_LAUNCH_PERSISTENT, pl.threads, pl.lds_bytes, persistent_grid(pl.wgs_per_cu));
-        if (!pl.owner_in_lds) e->owner_tagged = true;
+        if (!pl.owner_in_lds) s.owner_tagged = true;
       }
     }
-    PHOVO_HIP_CHECK(hipEventRecord(e->ev_stop[l], e->stream));
-    e->level_launched[l] = true;
+    PHOVO_HIP_CHECK(hipEventRecord(s.ev_stop[l], s.stream));
+    s.level_launched[l] = true;
   }
-  PHOVO_HIP_CHECK(hipEventRecord(e->ev_total_stop, e->stream));
-  e->have_timing = true;
+  PHOVO_HIP_CHECK(hipEventRecord(s.ev_total_stop, s.stream));
+  s.have_timing = true;
   return PHOVO_OK;
 }
+
+// The slot that holds enqueue `ticket`, or null when that enqueue never happened or its slot has been taken over since.
+static AlignSlot *slot_of(phovo_engine *e, int ticket)
+{
+  if (!e || ticket <= 0 || ticket > e->ticket) return nullptr;
+  AlignSlot &s = e->slots[ticket % PHOVO_ENQUEUE_DEPTH];
+  return s.ticket == ticket ? &s : nullptr;
+}
+static const AlignSlot *slot_of(const phovo_engine *e, int ticket) { return slot_of(const_cast<phovo_engine *>(e), ticket); }
+static const char *const STALE_TICKET = "no such enqueue in flight (tickets stay valid until PHOVO_ENQUEUE_DEPTH later enqueues)";
+
+int phovo_engine_last_ticket(const phovo_engine *e) { return e ? e->ticket : 0; }
 
 int phovo_engine_last_launches(const phovo_engine *e, phovo_launch_record *out, int capacity, int *count)
 {
   if (!e || !count) return fail(PHOVO_E_INVALID_ARGUMENT, "last_launches: null");
-  *count = (int)e->launches.size();
-  if (out)
-    for (int i = 0; i < capacity && i < *count; i++) out[i] = e->launches[(size_t)i];
+  const AlignSlot *s = slot_of(e, e->ticket);
+  *count = s ? (int)s->launches.size() : 0;
+  if (out && s)
+    for (int i = 0; i < capacity && i < *count; i++) out[i] = s->launches[(size_t)i];
   return PHOVO_OK;
 }
 
@@ -1137,23 +1189,35 @@ int phovo_engine_synchronize(phovo_engine *e)
   if (!e) return fail(PHOVO_E_INVALID_ARGUMENT, "synchronize: null");
   PHOVO_HIP_CHECK(hipSetDevice(e->device));
   PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
+  PHOVO_HIP_CHECK(quiesce(e));
   return PHOVO_OK;
 }
 
-int phovo_engine_fetch_results(phovo_engine *e, int n_pairs, double *out_states, phovo_pair_report *reports)
+int phovo_engine_wait(phovo_engine *e, int ticket)
 {
-  if (!e) return fail(PHOVO_E_INVALID_ARGUMENT, "fetch_results: null");
-  if (n_pairs != e->last_pairs) return fail(PHOVO_E_INVALID_ARGUMENT, "fetch_results: n_pairs differs from the last enqueue");
+  AlignSlot *s = slot_of(e, ticket);
+  if (!s) return fail(PHOVO_E_INVALID_ARGUMENT, std::string("wait: ") + STALE_TICKET);
+  PHOVO_HIP_CHECK(hipSetDevice(e->device));
+  PHOVO_HIP_CHECK(hipStreamSynchronize(s->stream));
+  return PHOVO_OK;
+}
+
+int phovo_engine_fetch(phovo_engine *e, int ticket, int n_pairs, double *out_states, phovo_pair_report *reports)
+{
+  if (!e) return fail(PHOVO_E_INVALID_ARGUMENT, "fetch: null");
+  AlignSlot *s = slot_of(e, ticket);
+  if (!s) return fail(PHOVO_E_INVALID_ARGUMENT, std::string("fetch: ") + STALE_TICKET);
+  if (n_pairs != s->last_pairs) return fail(PHOVO_E_INVALID_ARGUMENT, "fetch: n_pairs differs from that enqueue's");
   if (n_pairs == 0) return PHOVO_OK;
   PHOVO_HIP_CHECK(hipSetDevice(e->device));
   const PairLayout pl = pair_layout(n_pairs);
   // one copy out: states (and reports right behind them, when asked for) into pinned memory
   const size_t bytes = (reports ? pl.heads : pl.reports) - pl.states;
-  PHOVO_HIP_CHECK(hipMemcpyAsync(e->h_down, e->d_pairs + pl.states, bytes, hipMemcpyDeviceToHost, e->stream));
-  PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
-  if (out_states) std::memcpy(out_states, e->h_down, sizeof(double) * 6 * (size_t)n_pairs);
+  PHOVO_HIP_CHECK(hipMemcpyAsync(s->h_down, s->d_pairs + pl.states, bytes, hipMemcpyDeviceToHost, s->stream));
+  PHOVO_HIP_CHECK(hipStreamSynchronize(s->stream));
+  if (out_states) std::memcpy(out_states, s->h_down, sizeof(double) * 6 * (size_t)n_pairs);
   if (reports) {
-    std::memcpy(reports, e->h_down + (pl.reports - pl.states), sizeof(phovo_pair_report) * (size_t)n_pairs);
+    std::memcpy(reports, s->h_down + (pl.reports - pl.states), sizeof(phovo_pair_report) * (size_t)n_pairs);
     // Levels with max_num_iterations == 0 still run the loop body once in the reference (:510,547-549).
     for (int i = 0; i < n_pairs; i++)
       for (int l = 0; l < e->cfg.num_levels; l++)
@@ -1162,10 +1226,27 @@ int phovo_engine_fetch_results(phovo_engine *e, int n_pairs, double *out_states,
   return PHOVO_OK;
 }
 
+int phovo_engine_fetch_results(phovo_engine *e, int n_pairs, double *out_states, phovo_pair_report *reports)
+{
+  if (!e) return fail(PHOVO_E_INVALID_ARGUMENT, "fetch_results: null");
+  if (e->ticket == 0) return n_pairs == 0 ? PHOVO_OK : fail(PHOVO_E_INVALID_ARGUMENT, "fetch_results: nothing has been enqueued");
+  return phovo_engine_fetch(e, e->ticket, n_pairs, out_states, reports);
+}
+
+int phovo_engine_device_states(phovo_engine *e, int ticket, void **states)
+{
+  if (!e || !states) return fail(PHOVO_E_INVALID_ARGUMENT, "device_states: null");
+  AlignSlot *s = slot_of(e, ticket);
+  if (!s) return fail(PHOVO_E_INVALID_ARGUMENT, std::string("device_states: ") + STALE_TICKET);
+  *states = s->d_states;
+  return PHOVO_OK;
+}
+
 int phovo_engine_results_device_ptr(phovo_engine *e, void **states)
 {
   if (!e || !states) return fail(PHOVO_E_INVALID_ARGUMENT, "results_device_ptr: null");
-  *states = e->d_states;
+  const AlignSlot *s = slot_of(e, e->ticket);
+  *states = s ? s->d_states : nullptr;
   return PHOVO_OK;
 }
 
@@ -1178,27 +1259,35 @@ int phovo_engine_align_pairs(phovo_engine *e, int n_pairs, const int *source_fra
   return phovo_engine_fetch_results(e, n_pairs, out_states, reports);
 }
 
-int phovo_engine_last_align_ms(const phovo_engine *e, double *total_ms, double level_ms[PHOVO_MAX_LEVELS])
+int phovo_engine_align_ms(const phovo_engine *e, int ticket, double *total_ms, double level_ms[PHOVO_MAX_LEVELS])
 {
-  if (!e) return fail(PHOVO_E_INVALID_ARGUMENT, "last_align_ms: null");
-  if (!e->have_timing) return fail(PHOVO_E_NOT_READY, "last_align_ms: nothing has been enqueued");
+  if (!e) return fail(PHOVO_E_INVALID_ARGUMENT, "align_ms: null");
+  const AlignSlot *s = slot_of(e, ticket);
+  if (!s || !s->have_timing) return fail(PHOVO_E_NOT_READY, "align_ms: nothing has been enqueued under that ticket");
   PHOVO_HIP_CHECK(hipSetDevice(e->device));
-  PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
+  PHOVO_HIP_CHECK(hipStreamSynchronize(s->stream));
   for (int l = 0; l < PHOVO_MAX_LEVELS; l++) {
     double ms = 0;
-    if (e->level_launched[l]) {
+    if (s->level_launched[l]) {
       float f = 0;
-      PHOVO_HIP_CHECK(hipEventElapsedTime(&f, e->ev_start[l], e->ev_stop[l]));
+      PHOVO_HIP_CHECK(hipEventElapsedTime(&f, s->ev_start[l], s->ev_stop[l]));
       ms = f;
     }
     if (level_ms) level_ms[l] = ms;
   }
-  if (total_ms) {           // first launch to last, once: the spans of consecutive levels may overlap (enqueue)
+  if (total_ms) {           // first launch to last
     float f = 0;
-    PHOVO_HIP_CHECK(hipEventElapsedTime(&f, e->ev_total_start, e->ev_total_stop));
+    PHOVO_HIP_CHECK(hipEventElapsedTime(&f, s->ev_total_start, s->ev_total_stop));
     *total_ms = f;
   }
   return PHOVO_OK;
+}
+
+int phovo_engine_last_align_ms(const phovo_engine *e, double *total_ms, double level_ms[PHOVO_MAX_LEVELS])
+{
+  if (!e) return fail(PHOVO_E_INVALID_ARGUMENT, "last_align_ms: null");
+  if (e->ticket == 0) return fail(PHOVO_E_NOT_READY, "last_align_ms: nothing has been enqueued");
+  return phovo_engine_align_ms(e, e->ticket, total_ms, level_ms);
 }
 
 int phovo_engine_level_launch_info(const phovo_engine *e, int level, int *threads, int *lds_bytes,

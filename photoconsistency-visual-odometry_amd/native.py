@@ -141,6 +141,11 @@ SYMBOLS = {
     "phovo_engine_last_align_ms": (C.c_int, [_vp, _dp, _dp]),
     "phovo_engine_level_launch_info": (C.c_int, [_vp, C.c_int, _ip, _ip, _ip, _ip]),
     "phovo_engine_last_launches": (C.c_int, [_vp, _vp, C.c_int, _ip]),
+    "phovo_engine_last_ticket": (C.c_int, [_vp]),
+    "phovo_engine_wait": (C.c_int, [_vp, C.c_int]),
+    "phovo_engine_fetch": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
+    "phovo_engine_device_states": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
+    "phovo_engine_align_ms": (C.c_int, [_vp, C.c_int, _dp, _dp]),
 }
 
 

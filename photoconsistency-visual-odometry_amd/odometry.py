@@ -325,6 +325,32 @@ class AlignmentEngine:
     def synchronize(self):
         check(self._lib.phovo_engine_synchronize(self._h), "phovo_engine_synchronize")
 
+    # -- pipelining (phovo_hip.h): PHOVO_ENQUEUE_DEPTH = 2 enqueues in flight, each under a ticket ----------------
+    def last_ticket(self):
+        return int(self._lib.phovo_engine_last_ticket(self._h))
+
+    def wait(self, ticket):
+        check(self._lib.phovo_engine_wait(self._h, int(ticket)), "phovo_engine_wait")
+
+    def fetch(self, ticket, n, want_reports=False):
+        out = np.zeros((n, 6))
+        reps = (native.PairReport * max(n, 1))() if want_reports else None
+        check(self._lib.phovo_engine_fetch(
+            self._h, int(ticket), int(n), out.ctypes.data, C.cast(reps, C.c_void_p) if reps is not None else None),
+            "phovo_engine_fetch")
+        return (out, list(reps)[:n]) if want_reports else out
+
+    def device_states(self, ticket):
+        p = C.c_void_p()
+        check(self._lib.phovo_engine_device_states(self._h, int(ticket), C.byref(p)), "phovo_engine_device_states")
+        return p.value
+
+    def align_ms(self, ticket):
+        total = C.c_double()
+        per = (C.c_double * native.MAX_LEVELS)()
+        check(self._lib.phovo_engine_align_ms(self._h, int(ticket), C.byref(total), per), "phovo_engine_align_ms")
+        return total.value, list(per)
+
     def fetch_results(self, n, want_reports=False):
         out = np.zeros((n, 6))
         reps = (native.PairReport * max(n, 1))() if want_reports else None

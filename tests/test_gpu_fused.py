@@ -160,3 +160,44 @@ def test_small_batches_and_thresholds_of_zero_take_one_launch_per_level():
         eng.align_pairs([0] * 64, [1] * 64)
         ls = eng.last_launches()
         assert [r["kind"] for r in ls] == ["persistent", "persistent"] and [r["threads"] for r in ls] == [256, 512], ls
+
+
+def test_two_enqueues_in_flight_change_nothing_but_the_clock():
+    """phovo_hip.h, "Pipelining": the engine keeps two enqueues in flight, each on its own stream with its own pair
+    buffers, so that the next batch's kernels fill the CUs the last long pairs of a batch leave idle.  Three batches issued
+    back to back and fetched one behind come out bit-identical to the same batches run one at a time; a ticket is refused
+    once two later enqueues have been issued; an upload issued while a batch is in flight waits for it (the batch still
+    sees the frames it was enqueued on)."""
+    ncfg = native.read_config_file(os.path.join(CFG_DIR, "config_4_level_optimization_analytic.yml"))
+    probs = _problems()
+    rs = np.random.RandomState(4)
+    batches = []
+    for n in (1800, 2300, 1500):
+        order = rs.randint(0, len(probs), size=n)
+        batches.append(([2 * int(i) for i in order], [2 * int(i) + 1 for i in order]))
+    with odometry.AlignmentEngine() as eng:
+        eng.set_config(ncfg)
+        eng.set_batch_invariant(True)
+        eng.set_intrinsic_matrix(probs[0]["K"])
+        _upload(eng, probs)
+        serial = [eng.align_pairs(s, t, want_reports=True) for s, t in batches]
+        tickets, got = [], {}
+        for k, (s, t) in enumerate(batches):
+            eng.enqueue_align(s, t)
+            tickets.append(eng.last_ticket())
+            if k > 0:
+                got[k - 1] = eng.fetch(tickets[k - 1], len(batches[k - 1][0]), want_reports=True)
+        assert tickets == [tickets[0], tickets[0] + 1, tickets[0] + 2]
+        with pytest.raises(native.PhovoError) as err:                 # two later enqueues have taken its slot
+            eng.fetch(tickets[0], len(batches[0][0]))
+        assert err.value.status == native.E_INVALID_ARGUMENT
+        # an upload while the last batch may still be running: it waits for the batch, which sees the old frame
+        blank = np.zeros_like(probs[0]["gray1"])
+        eng.upload_frame(1, blank, None, roles=native.ROLE_TARGET)
+        got[2] = eng.fetch(tickets[2], len(batches[2][0]), want_reports=True)
+        total_ms, _ = eng.align_ms(tickets[2])
+        assert total_ms > 0.0
+    for k in range(3):
+        assert np.array_equal(got[k][0], serial[k][0]), k
+        assert all(list(a.iterations[:4]) == list(b.iterations[:4]) and a.gradient_norm == b.gradient_norm and a.flags == b.flags
+                   for a, b in zip(got[k][1], serial[k][1])), k

@@ -10,7 +10,7 @@ def line(text, tag=""):
     rt = d.get("reference_termination") or {}
     print(tag, round(d["value"]), round(d["ms_per_step"], 3), "frac", round(d["roofline"]["frac"], 3),
           "all", round(d["roofline"]["all_levels_frac"], 3), lv, "its", [round(v, 2) for v in d["iterations_per_pair"]],
-          "ref-term", round(rt.get("value", 0)))
+          "ref-term", round(rt.get("value", 0)), "serial", round((d.get("one_enqueue_at_a_time") or {}).get("value", 0)))
 
 
 if len(sys.argv) == 3 and not sys.argv[2].endswith(".json"):      # file, tag
