@@ -203,25 +203,33 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const unsigned char
 {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(p), 0, n * (int)sizeof(T), 0x00020000);
 }
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t frame_rsrc(const unsigned char *frame, size_t frame_bytes)
+{
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(frame), 0, (int)frame_bytes, 0x00020000);
+}
 // Element `idx` of a plane stored as T, widened to fp64 (all arithmetic stays fp64; narrower storage is the
 // opt-in extension of include/phovo_hip.h, PHOVO_STORAGE_*).  idx = -1 or past the plane reads 0.
+// soff: a wave-uniform byte offset (the instruction's scalar offset; it takes part in the range check): one descriptor
+// per FRAME (frame_rsrc) serves every plane of it -- base = the frame, soff = the plane's offset in it.  Four SGPRs per
+// frame plus one per plane instead of four per plane: the level kernels run out of scalar registers, and every spilled
+// one costs a v_readlane per use in the pixel loops.
 template <typename T>
-__device__ __forceinline__ double plane_load(__amdgpu_buffer_rsrc_t r, int idx);
+__device__ __forceinline__ double plane_load(__amdgpu_buffer_rsrc_t r, int idx, int soff = 0);
 template <>
-__device__ __forceinline__ double plane_load<double>(__amdgpu_buffer_rsrc_t r, int idx)
+__device__ __forceinline__ double plane_load<double>(__amdgpu_buffer_rsrc_t r, int idx, int soff)
 {
-  const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, idx * 8, 0, 0);
+  const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, idx * 8, soff, 0);
   return __hiloint2double((int)v.y, (int)v.x);
 }
 template <>
-__device__ __forceinline__ double plane_load<float>(__amdgpu_buffer_rsrc_t r, int idx)
+__device__ __forceinline__ double plane_load<float>(__amdgpu_buffer_rsrc_t r, int idx, int soff)
 {
-  return (double)__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, idx * 4, 0, 0));
+  return (double)__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, idx * 4, soff, 0));
 }
 template <>
-__device__ __forceinline__ double plane_load<__half>(__amdgpu_buffer_rsrc_t r, int idx)
+__device__ __forceinline__ double plane_load<__half>(__amdgpu_buffer_rsrc_t r, int idx, int soff)
 {
-  const unsigned short bits = __builtin_amdgcn_raw_buffer_load_b16(r, idx * 2, 0, 0);
+  const unsigned short bits = __builtin_amdgcn_raw_buffer_load_b16(r, idx * 2, soff, 0);
   return (double)__half2float(__ushort_as_half(bits));
 }
 
@@ -257,13 +265,17 @@ __device__ __forceinline__ void plane_load2<__half>(__amdgpu_buffer_rsrc_t r, in
 // 1/x to within one ulp: v_rcp_f64 seeds two Newton steps.  The IEEE-exact division sequence is
 // 11 instructions, this is 5; the half-ulp it gives up is far below the fp64 noise floor of the sums
 // that follow (tests/test_gpu_parity.py holds the poses to 1e-9 against the oracle's exact divisions).
+template <int STEPS = 2>
 __device__ __forceinline__ double fast_rcp(double x)
 {
   double r = __builtin_amdgcn_rcp(x);
   double e = fma(-x, r, 1.0);
   r = fma(r, e, r);
-  e = fma(-x, r, 1.0);
-  return fma(r, e, r);
+  if (STEPS >= 2) {
+    e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+  }
+  return r;
 }
 
 // Entries of an owner map kept in HBM: (iteration tag << 21) | source index.  atomicMax still picks the largest

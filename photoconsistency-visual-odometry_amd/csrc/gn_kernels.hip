@@ -83,11 +83,13 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
   const unsigned char *src_frame = A.planes + (size_t)A.src[pair] * A.frame_bytes;
   const unsigned char *tgt_frame = A.planes + (size_t)A.tgt[pair] * A.frame_bytes;
   int *g_owner = OWNER_LDS ? nullptr : A.g_owner + (size_t)pair * (size_t)n;
-  const __amdgpu_buffer_rsrc_t rI0 = plane_rsrc<TI>(src_frame + A.plane_off[PLANE_I], n);
-  const __amdgpu_buffer_rsrc_t rD0 = plane_rsrc<TD>(src_frame + A.plane_off[PLANE_D], n);
-  const __amdgpu_buffer_rsrc_t rI1 = plane_rsrc<TI>(tgt_frame + A.plane_off[PLANE_I], n);
-  const __amdgpu_buffer_rsrc_t rGX = plane_rsrc<TI>(tgt_frame + A.plane_off[PLANE_GX], n);
-  const __amdgpu_buffer_rsrc_t rGY = plane_rsrc<TI>(tgt_frame + A.plane_off[PLANE_GY], n);
+  // ONE descriptor per frame, the plane chosen by a scalar offset (plane_load): the hardware checks voffset + soffset
+  // against num_records, so the bound is the frame's -- an index past its plane reads the next plane of the same frame
+  // (the chunk-ahead prefetches do that: those lanes are masked out of every use) and never leaves the frame; the index
+  // -1 of "no owner" wraps to the top of the address range and still reads 0.
+  const __amdgpu_buffer_rsrc_t rS = frame_rsrc(src_frame, A.frame_bytes), rT = frame_rsrc(tgt_frame, A.frame_bytes);
+  const int oI = (int)A.plane_off[PLANE_I], oD = (int)A.plane_off[PLANE_D];
+  const int oGX = (int)A.plane_off[PLANE_GX], oGY = (int)A.plane_off[PLANE_GY];
 
   // ---- level prologue -------------------------------------------------------------------
   // (a level that follows another one in the same workgroup: every wave must have read the previous level's last
@@ -101,7 +103,7 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   }
   if (SRC_LDS) {
-    for (int k = tid; k < n; k += T) s_i0[k] = plane_load<TI>(rI0, k);
+    for (int k = tid; k < n; k += T) s_i0[k] = plane_load<TI>(rS, k, oI);
   }
   if (wave == 0) {
     double st[6];
@@ -120,18 +122,22 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
   const double fx = A.fx, fy = A.fy, ox = A.ox, oy = A.oy, ifx = A.ifx, ify = A.ify;
   const double min_d = A.min_depth, max_d = A.max_depth;
   const double dW = (double)W, dH = (double)H;
+  // px = (c - ox) * pz * ifx (:282) as fma(c + 0.5, ifx, -(ox + 0.5) * ifx) * pz: one fma and one product
+  const double oxi = uniform_f64(-(ox + 0.5) * ifx), oyi = uniform_f64(-oy * ify);
   const double huber_delta = A.huber_delta;
   const bool huber_on = huber_delta > 0.0;
 
   // A wave walks the image in chunks of 64 consecutive pixels, NW chunks apart; (row, column) of a
   // lane's pixel is carried along instead of divided out per pixel.
   const int k0 = wave * WAVE + lane;
-  // (row, column) of a lane's pixel from its linear index, carried as a double: four instructions per chunk (add, fma,
-  // trunc, fma) instead of the six of a carried pair with compare-and-wrap, and two registers less across the loops
-  const RowColFromIndex rc_map = make_rowcol_from_index(W);
-  const double kd0 = (double)k0, kd_step = (double)(NW * WAVE);
+  // (row, column) of a lane's pixel from its linear index, carried as the double k + 0.5: row = trunc((k + 0.5) / W) -- the
+  // quotient lies at least 0.5 / W >= 2.4e-7 away from every integer, its product form is off by less than 1e-12, so the
+  // truncation is exact -- and column + 0.5 = (k + 0.5) - row * W, an exact integer fma; the half pixel is folded into the
+  // constant of the unprojection below.  Four instructions per chunk (add, mul, trunc, fma), three scalar constants.
+  const double inv_w = uniform_f64(1.0 / dW);
+  const double kd0 = (double)k0 + 0.5, kd_step = (double)(NW * WAVE);
 #define PHOVO_ROWCOL_BEGIN double kd = kd0, cd, rd;
-#define PHOVO_ROWCOL_HERE rowcol_from_index(kd, rc_map, cd, rd);
+#define PHOVO_ROWCOL_HERE { rd = trunc(kd * inv_w); cd = fma(-rd, dW, kd); }
 #define PHOVO_ROWCOL_NEXT kd += kd_step;
 
   while (true) {
@@ -139,8 +145,12 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
     const double cx = uniform_f64(s_cst[C_X]), cyy = uniform_f64(s_cst[C_Y]), cz = uniform_f64(s_cst[C_Z]);
     const double r01 = uniform_f64(s_cst[C_R01]), r02 = uniform_f64(s_cst[C_R02]);
     const double r11 = uniform_f64(s_cst[C_R11]), r12 = uniform_f64(s_cst[C_R12]);
+    // the two projected rows of Rt already multiplied by the focal lengths (pass 1 only): (X*fx)*iz + ox (:295) becomes
+    // one fma on X*fx built directly -- eight products per iteration and wave instead of two per pixel
+    const double fr00 = uniform_f64(uniform_f64(s_cst[C_T15]) * fx), fr01 = uniform_f64(r01 * fx), fr02 = uniform_f64(r02 * fx);
+    const double fr10 = uniform_f64(uniform_f64(s_cst[C_T14]) * fy), fr11 = uniform_f64(r11 * fy), fr12 = uniform_f64(r12 * fy);
     const double t1 = uniform_f64(s_cst[C_T1]), t2 = uniform_f64(s_cst[C_T2]), t3 = uniform_f64(s_cst[C_T3]);
-    const double t14 = uniform_f64(s_cst[C_T14]), t15 = uniform_f64(s_cst[C_T15]);
+    const double t14 = uniform_f64(s_cst[C_T14]);
 
     // Owner map in HBM: this iteration's tag (1..OWNER_TAG_PERIOD); when the tags start over the map is wiped.
     int owner_tag = 0;
@@ -164,10 +174,10 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
       PHOVO_ROWCOL_BEGIN
       // software prefetch: the depth of the NEXT chunk is requested before this chunk is processed, so
       // every wave keeps a load in flight while it computes (the passes are bound by bytes in flight per CU)
-      double pz_next = plane_load<TD>(rD0, k);
+      double pz_next = plane_load<TD>(rS, k, oD);
       // the translation sits in vector registers during this pass (pass 1 has registers to spare): an fma takes one
       // scalar operand, and the rotation entry already is one
-      double cxv = cx, cyv = cyy, czv = cz;
+      double cxv = cx * fx, cyv = cyy * fy, czv = cz;
       asm volatile("" : "+v"(cxv), "+v"(cyv), "+v"(czv));
       // warp of one 64-pixel chunk: ballot of "valid and landed in bounds" and the target index of every lane
       auto warp_chunk = [&](const double pz, const int chunk, unsigned long long &m_out, int &t_out) {
@@ -176,14 +186,14 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
         // the AND of the compare masks -- scalar work only.
         // depth gate: k < n, min_d < pz < max_d  (:280), folded into the ballot below
         PHOVO_ROWCOL_HERE
-        const double px = (cd - ox) * pz * ifx;                           // :282
-        const double py = (rd - oy) * pz * ify;                           // :283
-        const double X = fma(r02, pz, fma(r01, py, fma(t15, px, cxv)));   // Rt*point3D  :291
-        const double Y = fma(r12, pz, fma(r11, py, fma(t14, px, cyv)));
+        const double px = fma(cd, ifx, oxi) * pz;                         // :282  ((c - ox) * ifx as one fma)
+        const double py = fma(rd, ify, oyi) * pz;                         // :283
+        const double Xf = fma(fr02, pz, fma(fr01, py, fma(fr00, px, cxv)));      // fx * (Rt*point3D).x  :291,295
+        const double Yf = fma(fr12, pz, fma(fr11, py, fma(fr10, px, cyv)));
         const double Z = fma(t2, pz, fma(t1, py, fma(-t3, px, czv)));
         const double iz = fast_rcp(Z);                                    // :294
-        const double tc = (X * fx) * iz + ox;                             // :295
-        const double tr = (Y * fy) * iz + oy;                             // :296
+        const double tc = fma(Xf, iz, ox);                                // :295
+        const double tr = fma(Yf, iz, oy);                                // :296
         // C round(), half away from zero (:297-298), then 0 <= . < size (:302-303): round(v) >= 0 iff v > -0.5
         // (NaN fails every comparison)
         const double rr = round_half_up_from(tr), rc = round_half_up_from(tc);
@@ -212,7 +222,7 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
       if constexpr (OWNER_LDS) {
         auto chunk_body = [&](const int chunk) {
           const double pz = pz_next;                                      // :279
-          pz_next = plane_load<TD>(rD0, k + NW * WAVE);                   // past the plane: 0
+          pz_next = plane_load<TD>(rS, k + NW * WAVE, oD);                   // (past the plane: masked out)
           unsigned long long m;
           int t;
           warp_chunk(pz, chunk, m, t);
@@ -242,11 +252,11 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
         unsigned long long pend_m[G];
         pzg[0] = pz_next;
 #pragma unroll
-        for (int g = 1; g < G; g++) pzg[g] = plane_load<TD>(rD0, k + g * NW * WAVE);
+        for (int g = 1; g < G; g++) pzg[g] = plane_load<TD>(rS, k + g * NW * WAVE, oD);
         int chunk = wave;
         while (chunk < A.n_chunks) {
 #pragma unroll
-          for (int g = 0; g < G; g++) pzn[g] = plane_load<TD>(rD0, k + (G + g) * NW * WAVE);     // past the plane: 0
+          for (int g = 0; g < G; g++) pzn[g] = plane_load<TD>(rS, k + (G + g) * NW * WAVE, oD);     // (past the plane: masked out)
           int count = 0;
 #pragma unroll
           for (int g = 0; g < G; g++) {
@@ -321,12 +331,12 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
           }
           owner_request(kk + NW * WAVE);
         }
-        pz_n = plane_load<TD>(rD0, kk);
-        gx_n = plane_load<TI>(rGX, kk);             // gradient at the SOURCE index  :346-347
-        gy_n = plane_load<TI>(rGY, kk);
-        i1_n = plane_load<TI>(rI1, kk);             // :309
+        pz_n = plane_load<TD>(rS, kk, oD);
+        gx_n = plane_load<TI>(rT, kk, oGX);             // gradient at the SOURCE index  :346-347
+        gy_n = plane_load<TI>(rT, kk, oGY);
+        i1_n = plane_load<TI>(rT, kk, oI);             // :309
         if (SRC_LDS) { if (o_n >= 0) i0_n = s_i0[o_n]; }
-        else i0_n = plane_load<TI>(rI0, o_n);       // :308 of the owning source pixel (o = -1: offset past the plane -> 0)
+        else i0_n = plane_load<TI>(rS, o_n, oI);       // :308 of the owning source pixel (o = -1: offset past the plane -> 0)
       };
       fetch(k);
       auto chunk_body = [&](const int chunk) {
@@ -340,8 +350,8 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
         if (__builtin_amdgcn_inverse_ballot_w64(mbits)) {                 // the ballot becomes the exec mask
           const double res = (o >= 0) ? (pixel2 - pixel1) : 0.0;          // :358
           PHOVO_ROWCOL_HERE
-          const double px = (cd - ox) * pz * ifx;
-          const double py = (rd - oy) * pz * ify;
+          const double px = fma(cd, ifx, oxi) * pz;
+          const double py = fma(rd, ify, oyi) * pz;
 
           // The 2x6 warp Jacobian (:312-342) contracted with the image gradient (:348), with the common
           // factors pulled out and the reference's temps folded by exact algebraic identities:
@@ -357,9 +367,9 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
           //   J4 = (J0*cos(yaw) + J1*sin(yaw))*(Zd - z) + Cm*J2,
           //   J5 = J0*(py*temp4+pz*temp21) + J1*(pz*temp7+py*temp9) + Dm*J2.
           const double Zr = py * t1 + pz * t2 - px * t3;                  // Zd - z
-          const double t25 = fast_rcp(cz + Zr);                           // :313
+          const double t25 = fast_rcp<1>(cz + Zr);                        // :313  (one Newton step: 2^-48, a Jacobian factor)
           const double Au = pz * t4 + py * t5 + px * t11;
-          const double Bv = py * t6 + pz * t9 + px * t14 + cyy;
+          const double Bv = fma(py, t6, fma(pz, t9, fma(px, t14, cyy)));
           const double Cm = -py * t16 - pz * t17 - px * t24;
           const double Dm = py * t2 - pz * t1;
           double J[6];
