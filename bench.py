@@ -35,6 +35,10 @@ PARITY_BAR = 1e-9             # ||log(T_gpu^-1 T_cpu)|| of the in-line self-chec
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 # headline workload (BASELINE.json configs[1] / configs[3]); --workload cfg5 switches to configs[4]'s shape
 WORKLOADS = {
+    # BASELINE.json configs[0]'s configuration, batched: level 0 only (307 200 pixels: the sliding-window kernel).  The yml's
+    # own max_num_iterations is 5000 with a threshold of 300; the fixed-iteration figure takes 5 iterations per pair.
+    "cfg1": dict(yml="config_only_level_0_analytic.yml", size=(640, 480), pairs=512, max_iterations="5",
+                 metric="frame-pair alignments/sec (640x480, level 0 only, 5 iterations; not the headline metric)"),
     "cfg2": dict(yml="config_4_level_optimization_analytic.yml", size=(640, 480),
                  metric="frame-pair alignments/sec (640x480, 4-level)"),
     "cfg3": dict(yml="config_5_level_optimization_analytic.yml", size=(640, 480),
@@ -49,7 +53,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=8192,
+    ap.add_argument("--pairs", type=int, default=None,
                     help="frame pairs per GPU per step (a level launch has ~0.13 ms of fixed cost: 2048 pairs run at "
                          "241 k alignments/s, 8192 at 253 k, 16384 at 254 k)")
     ap.add_argument("--distinct", type=int, default=32, help="distinct synthetic pairs generated per GPU")
@@ -63,6 +67,8 @@ def parse():
                     help="plane storage (f64 = reference-exact; arithmetic is fp64 in every mode)")
     ap.add_argument("--huber", type=float, default=0.0, help="Huber delta on every level (0 = off)")
     ap.add_argument("--bilinear", action="store_true", help="bilinear forward-additive sampling + corrected Jacobian")
+    ap.add_argument("--bilinear-gather", action="store_true",
+                    help="with --bilinear: the form that gathers every tap from global memory (A/B of the LDS-staged form)")
     ap.add_argument("--max-iterations", default=None,
                     help="diagnostic, never the default: comma list overriding the yml's max_num_iterations, level 0 first "
                          "(e.g. 0,0,1,1 = every plane streamed exactly once: the HBM-only rate of the level kernels)")
@@ -79,7 +85,8 @@ def parse():
                     help="synthetic scene: the slanted textured plane (default) or the layered desk-like scene with depth "
                          "discontinuities, invalid regions and depth noise (synthetic.py)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2",
-                    help="cfg2 = the headline 640x480 4-level workload; cfg3 = BASELINE.json configs[2]'s configuration "
+                    help="cfg1 = BASELINE.json configs[0]'s configuration batched (level 0 only); "
+                         "cfg2 = the headline 640x480 4-level workload; cfg3 = BASELINE.json configs[2]'s configuration "
                          "(640x480, config_5_level); cfg5 = configs[4]'s shape (1280x960, config_6_level; combine with "
                          "--storage f16 --huber 0.05)")
     return ap.parse_args()
@@ -88,6 +95,85 @@ def parse():
 def algorithmic_bytes(level_sizes, iterations):
     """per GN iteration and pair, 5 fp64 planes of N_L pixels are read once."""
     return sum(5.0 * 8.0 * n * it for n, it in zip(level_sizes, iterations))
+
+
+KERNEL_NAMES = {"persistent": "gn_level_kernel", "fused": "gn_fused_kernel", "slide": "gn_level_kernel_slide",
+                "slide_fallback": "gn_level_kernel", "wide": "k_wide_pass1 + k_wide_pass2", "bilinear": "gn_level_kernel_bilinear",
+                "bilinear_lds": "gn_level_kernel_bilinear_lds"}
+
+
+def launch_rows(launches, per_level_ms, steps, iters, level_sizes, plane_bytes, max_iter, n_pairs, storage_types):
+    """One row per kernel launch of a step, from the engine's own launch records (phovo_engine_last_launches): the levels
+    it covers, its kernel, its share of the algorithmic bytes and its average duration (the HIP-event span the engine
+    reports at the launch's coarsest level; the exact launch behind a sliding-window launch is inside that span)."""
+    rows = []
+    for rec in launches:
+        if rec["kind"] == "slide_fallback":
+            rows[-1]["followed_by"] = f"gn_level_kernel<{rec['threads']}, ...> on the pairs that left the window"
+            continue
+        lv = [l for l in rec["levels"] if max_iter[l] > 0]
+        pair_it = {str(l): float(iters[:, l].sum()) for l in lv}
+        nbytes = sum(plane_bytes * level_sizes[l] * pair_it[str(l)] for l in lv)
+        ms = per_level_ms[lv[0]] / steps
+        rows.append(dict(levels=lv, pixels=[level_sizes[l] for l in lv], kind=rec["kind"],
+                         kernel=f"{KERNEL_NAMES[rec['kind']]}<{rec['threads']}, ... {storage_types}>",
+                         threads=rec["threads"], lds_bytes=rec["lds_bytes"], workgroups=rec["workgroups"],
+                         avg_launch_ms=ms, pair_iterations_per_level=pair_it,
+                         iterations_per_pair={k: v / n_pairs for k, v in pair_it.items()},
+                         algorithmic_bytes=nbytes, achieved_GBs=nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0))
+    return rows
+
+
+def profile_context(kernel, pairs):
+    """What the committed rocprofv3 counter passes (profiles/, newest round first) hold for `kernel` (the name form of
+    launch_rows) at `pairs` pairs per launch: HBM-side bytes per launch, vector-unit busy fraction and vector instructions
+    per launch, and the rate at which the same kernel streams planes it reads exactly once (pure HBM)."""
+    import csv
+    import re
+    out = {}
+    fam, threads, types = re.match(r"([\w +]+)<(\d+), \.\.\. (.*)>", kernel).groups()
+
+    def same(name):
+        m = re.search(r"(\w+)<(\d+),", name)
+        return bool(m) and m.group(1) == fam and int(m.group(2)) == int(threads) and types in name
+
+    prof = os.path.join(ROOT, "profiles")
+    for tag in ("r04", "r03"):
+        for f in sorted(os.listdir(prof)):
+            if not (f.startswith(tag + "_") and f.endswith("_pmc_traffic.json")) or "stream_once" in f:
+                continue
+            try:
+                for kd in json.load(open(os.path.join(prof, f))).get("kernels", []):
+                    if same(kd.get("kernel", "")) and kd.get("pairs") == pairs and "traffic" not in out:
+                        out["traffic"] = kd["hbm_bytes_per_launch"]
+                        out["traffic_source"] = f"profiles/{f} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, calibrated)"
+                sq = os.path.join(prof, f.replace("_pmc_traffic.json", "_pmc_sq.json"))
+                if os.path.exists(sq):
+                    for kd in json.load(open(sq)).get("kernels", []):
+                        if same(kd.get("kernel", "")) and kd.get("pairs") == pairs and "valu" not in out:
+                            share = kd["fraction_of_wave_cycles"]["issuing VALU (SQ_ACTIVE_INST_VALU)"]
+                            waves = kd.get("waves_per_simd", 4)
+                            out["valu"] = dict(busy=share * waves, waves_per_simd=waves,
+                                               instructions_per_launch=kd["counters"].get("SQ_INSTS_VALU"),
+                                               effective_clock_GHz=kd.get("effective_clock_GHz"),
+                                               source=f"profiles/{os.path.basename(sq)} (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x waves per SIMD)")
+            except Exception:
+                pass
+        so = os.path.join(prof, tag + "_stream_once_pmc_traffic.json")
+        st = os.path.join(prof, tag + "_stream_once_kernel_stats.csv")
+        if "hbm_stream_measured" not in out and os.path.exists(so) and os.path.exists(st):
+            try:
+                ns = {r["Name"]: float(r["AverageNs"]) for r in csv.DictReader(open(st))}
+                for kd in json.load(open(so)).get("kernels", []):
+                    if same(kd.get("kernel", "")) and kd["kernel"] in ns:
+                        out["hbm_stream_measured"] = dict(
+                            GBs=kd["hbm_bytes_per_launch"] / ns[kd["kernel"]],
+                            source=f"profiles/{tag}_stream_once_*: this kernel with one iteration per pair (every plane read "
+                                   "exactly once per launch: pure HBM); the timed run's traffic above that rate is "
+                                   "Infinity-Cache hits (DESIGN.md 5.0)")
+            except Exception:
+                pass
+    return out
 
 
 ZERO_COPY = {"ok": None}      # None = not probed yet; decided once by probe_zero_copy() outside the timed region
@@ -189,6 +275,10 @@ def main():
     import phovo_amd  # noqa: F401
     from phovo_amd import distributed, native, odometry, se3, synthetic
     wl = WORKLOADS[args.workload]
+    if args.pairs is None:
+        args.pairs = wl.get("pairs", 8192)
+    if args.max_iterations is None and wl.get("max_iterations") and args.thresholds == "fixed":
+        args.max_iterations = wl["max_iterations"]
     YML = os.path.join(ROOT, "config_files", wl["yml"])
     W, H = wl["size"]
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -260,6 +350,8 @@ def main():
             plane_storage=storage_code, huber_delta=[args.huber] * nl,
             sampling=native.SAMPLING_BILINEAR if args.bilinear else native.SAMPLING_NEAREST_SCATTER,
             jacobian_corrected=args.bilinear))
+    if args.bilinear_gather:
+        eng.set_bilinear_policy(-1)
     eng.set_config(cfg_fixed)
     eng.set_intrinsic_matrix(seq["K"])
     n_frames = reps * (distinct + 1)
@@ -275,7 +367,6 @@ def main():
     n_local = len(src)
     n_global = n_local * world
     level_sizes = [eng.level_size(l)[0] * eng.level_size(l)[1] for l in range(nl)]
-    launch = {l: eng.level_launch_info(l) for l in range(nl) if max_iter[l] > 0}
 
     def barrier():
         if use_dist:
@@ -313,62 +404,42 @@ def main():
     value = n_global * args.steps / wall
     ms_per_step = 1e3 * wall / args.steps
 
-    # per-level roofline: algorithmic bytes of one launch / its average duration (HIP events on the
-    # engine's own stream, one start/stop pair around each level launch)
-    levels_out = []
-    for l in range(nl):
-        if max_iter[l] <= 0:
-            continue
-        it_sum = float(iters[:, l].sum())
-        bytes_launch = plane_bytes * level_sizes[l] * it_sum
-        avg_ms = per_level_ms[l] / args.steps
-        levels_out.append(dict(level=l, pixels=level_sizes[l], avg_launch_ms=avg_ms,
-                               iterations_per_pair=it_sum / n_local,
-                               algorithmic_bytes=bytes_launch,
-                               achieved_GBs=bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
-                               **launch[l]))
+    # per-launch roofline: algorithmic bytes of one launch / its average duration (HIP events on the enqueue's own
+    # stream, one start/stop pair around each launch; a fused launch covers several levels)
+    levels_out = launch_rows(timed_launches, per_level_ms, args.steps, iters, level_sizes, plane_bytes, max_iter, n_local,
+                             {"f64": "double, double", "f32": "float, float", "f16": "__half, float"}[args.storage])
     dom = max(levels_out, key=lambda d: d["avg_launch_ms"])
     total_bytes = sum(d["algorithmic_bytes"] for d in levels_out)
     total_ms = per_level_ms[native.MAX_LEVELS] / args.steps       # device time of a whole enqueue (HIP events, first launch to last)
-    roofline = dict(bound="hbm", kernel=f"gn_level_kernel level {dom['level']} ({dom['pixels']} px)",
+    roofline = dict(bound="hbm", kernel=dom["kernel"], levels_of_kernel=dom["levels"],
                     achieved=dom["achieved_GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=dom["achieved_GBs"] / HBM_PEAK_GBS, traffic=None,
                     all_levels_achieved=total_bytes / (total_ms * 1e-3) / 1e9,
                     all_levels_frac=total_bytes / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    levels=levels_out)
-    # HBM bytes per launch of the dominant kernel from the PMC counters: collected in separate rocprofv3 --pmc
-    # passes of this same command and calibrated (profiles/README.md); cannot be measured from inside the run.
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    storage_types = {"f64": "double, double>", "f32": "float, float>", "f16": "__half, float>"}
+                    launches=levels_out)
+    # What the PMC counters say about that kernel: collected in separate rocprofv3 --pmc passes of this same command
+    # (profiles/README.md; they cannot be measured from inside the run) -- HBM-side traffic per launch (FETCH_SIZE + WRITE_SIZE,
+    # calibrated) and how busy the vector units are (SQ_ACTIVE_INST_VALU).  `bound` names whichever of the two is nearer
+    # saturation: this path's arithmetic is fp64 on the vector unit, and with narrow plane storages or few re-reads from HBM
+    # that unit, not the memory system, is what the kernel waits for.
     plain_mode = args.huber == 0.0 and not args.bilinear      # the counters were collected on the reference path
-    if os.path.exists(pmc):
-        try:
-            for kd in json.load(open(pmc)).get("kernels", []):
-                if (kd.get("threads") == dom["threads"] and kd.get("pairs") == n_local and plain_mode
-                        and storage_types[args.storage] in kd.get("kernel", "")):
-                    roofline["traffic"] = kd["hbm_bytes_per_launch"]
-                    roofline["traffic_over_algorithmic"] = kd["hbm_bytes_per_launch"] / dom["algorithmic_bytes"]
-                    roofline["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, calibrated)"
-        except Exception:
-            pass
-
-    # How much of that traffic can be HBM at all: the same kernels profiled with every plane streamed exactly once per
-    # launch (profiles/r02_stream_once_*, `--max-iterations 0,0,1,1`: nothing can hit the Infinity Cache).  Context for
-    # `frac`, which divides algorithmic bytes by the spec peak and says nothing about where the re-reads are served.
-    try:
-        import csv
-        tag = next(t for t in ("r03_stream_once", "r02_stream_once")
-                   if os.path.exists(os.path.join(ROOT, "profiles", t + "_pmc_traffic.json")))
-        so = json.load(open(os.path.join(ROOT, "profiles", tag + "_pmc_traffic.json")))
-        st = {r["Name"]: float(r["AverageNs"]) for r in csv.DictReader(open(os.path.join(ROOT, "profiles", tag + "_kernel_stats.csv")))}
-        for kd in so.get("kernels", []):
-            if kd.get("threads") == dom["threads"] and plain_mode and args.storage == "f64" and kd["kernel"] in st:
-                roofline["hbm_only_stream_GBs"] = kd["hbm_bytes_per_launch"] / st[kd["kernel"]]
-                roofline["hbm_only_stream_source"] = (f"profiles/{tag}_*: this kernel with one iteration per pair, 8192 pairs "
-                                                      "(6.5 GB pool read once: pure HBM); the timed run's traffic above that rate is "
-                                                      "Infinity-Cache hits (DESIGN.md 5.0)")
-    except Exception:
-        pass
+    ctx = profile_context(dom["kernel"], n_local if plain_mode or args.bilinear else -1)
+    if ctx.get("traffic") is not None:
+        roofline["traffic"] = ctx["traffic"]
+        roofline["traffic_over_algorithmic"] = ctx["traffic"] / dom["algorithmic_bytes"]
+        roofline["traffic_GBs"] = ctx["traffic"] / (dom["avg_launch_ms"] * 1e-3) / 1e9
+        roofline["traffic_source"] = ctx["traffic_source"]
+    if ctx.get("valu") is not None:
+        v = dict(ctx["valu"])
+        chunk_iterations = sum(dom["pair_iterations_per_level"][str(l)] * ((level_sizes[l] + 63) // 64) for l in dom["levels"])
+        if v.get("instructions_per_launch") and chunk_iterations > 0:
+            v["wave_instructions_per_64_pixel_iteration"] = v["instructions_per_launch"] / chunk_iterations
+        roofline["valu"] = v
+        mem_sat = roofline.get("traffic_GBs", dom["achieved_GBs"]) / HBM_PEAK_GBS
+        roofline["saturation"] = {"hbm_side_traffic_over_peak": mem_sat, "vector_unit_busy": v["busy"]}
+        roofline["bound"] = "valu" if v["busy"] > mem_sat else "hbm"
+    if ctx.get("hbm_stream_measured") is not None:
+        roofline["hbm_stream_measured"] = ctx["hbm_stream_measured"]
 
     # ---- shipped thresholds (reference termination), same resident inputs ---------------------
     ref_term = None

@@ -13,6 +13,7 @@ namespace phovo_hip {
 namespace {
 
 constexpr int WAVE = 64;
+constexpr size_t LDS_LIMIT = 160 * 1024;   // MI355X: 160 KiB per CU, one workgroup may take all of it
 constexpr int NRED = 32;     // padded for the butterfly
 constexpr int RED_VALID = 27;   // slot behind the 21 + 6 sums: the number of Jacobian rows filled (lane 0 of every wave puts
                                 // its wave's count there as a double -- exact -- and the reduction adds them up for free)
@@ -26,6 +27,12 @@ enum {
 
 // Control words in LDS.
 enum { CTL_DONE = 0, CTL_FLAGS = 1, CTL_PAIR = 2, CTL_OOW = 3, CTL_COUNT = 4 };      // CTL_OOW: sliding-window kernel only
+
+// LDS every level kernel needs beside its maps: pose constants [32], state [8], one row of NRED wave sums per wave, control words
+__host__ __device__ constexpr size_t lds_fixed_bytes(int threads)
+{
+  return sizeof(double) * (32 + 8 + (size_t)(threads / WAVE) * NRED) + sizeof(int) * CTL_COUNT;
+}
 
 __device__ __forceinline__ double uniform_f64(double v)
 {

@@ -26,7 +26,7 @@ CSRC = os.path.join(ROOT, "photoconsistency-visual-odometry_amd", "csrc")
 def kernels():
     subprocess.run(["make", "-s", "-C", CSRC, "isa"], check=True, capture_output=True)
     out = {}
-    for name, least in (("gn_kernels.s", 18), ("gn_slide_kernel.s", 3)):
+    for name, least in (("gn_kernels.s", 18), ("gn_slide_kernel.s", 3), ("gn_bilinear_kernel.s", 12)):
         lines = open(os.path.join(CSRC, "build", name)).read().split("\n")
         starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN9phovo_hip.*gn_(level|fused)_kernel.*:", l)]
         assert len(starts) >= least, f"{name}: expected every storage x variant instantiation of the level kernels"
@@ -74,7 +74,7 @@ def test_work_loop_head_is_the_barrier(kernels):
 def test_every_barrier_waits_for_lds_first():
     subprocess.run(["make", "-s", "-C", CSRC, "isa"], check=True, capture_output=True)
     total = 0
-    for name in ("gn_kernels", "gn_slide_kernel", "gn_wide_kernels", "pyramid_kernels", "warp_kernels"):
+    for name in ("gn_kernels", "gn_bilinear_kernel", "gn_slide_kernel", "gn_wide_kernels", "pyramid_kernels", "warp_kernels"):
         lines = open(os.path.join(CSRC, "build", name + ".s")).read().split("\n")
         for i, l in enumerate(lines):
             if l.strip() != "s_barrier":

@@ -47,7 +47,7 @@ def sq_summary(rows, pairs):
     acc = defaultdict(lambda: defaultdict(list))
     dur = defaultdict(dict)
     for r in rows:
-        if "gn_level_kernel" not in r["Kernel_Name"]:
+        if "gn_level_kernel" not in r["Kernel_Name"] and "gn_fused_kernel" not in r["Kernel_Name"]:
             continue
         acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         dur[r["Kernel_Name"]][r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
@@ -66,8 +66,11 @@ def sq_summary(rows, pairs):
                 "issuing (SQ_ACTIVE_INST_ANY)": m.get("SQ_ACTIVE_INST_ANY", 0.0) / wc,
                 "issuing VALU (SQ_ACTIVE_INST_VALU)": m.get("SQ_ACTIVE_INST_VALU", 0.0) / wc,
             }
-            # 4 waves per SIMD share one vector unit: the per-wave VALU share times 4 is the unit's busy fraction
-            e["simd_valu_busy_at_4_waves"] = 4.0 * m.get("SQ_ACTIVE_INST_VALU", 0.0) / wc
+            # the waves of a SIMD share one vector unit: the per-wave VALU share times the resident waves per SIMD is the
+            # unit's busy fraction (4 for the 64- / 256- / 512- / 1024-thread level kernels and the fused kernel in a full
+            # launch; 2 for the sliding-window and the bilinear kernel, which take 256 registers)
+            e["waves_per_simd"] = 2 if ("gn_level_kernel_slide" in k or "gn_level_kernel_bilinear" in k) else 4
+            e["simd_valu_busy"] = e["waves_per_simd"] * m.get("SQ_ACTIVE_INST_VALU", 0.0) / wc
         if ns > 0 and "GRBM_GUI_ACTIVE" in m:
             e["effective_clock_GHz"] = m["GRBM_GUI_ACTIVE"] / 8.0 / ns
         out.append(e)
@@ -100,7 +103,7 @@ def main():
     fetch, nf = mean_by_kernel(counter_rows(os.path.join(src, "pmc_fetch")), skip_first=2)
     write, _ = mean_by_kernel(counter_rows(os.path.join(src, "pmc_write")), skip_first=2)
     for (k, g), v in sorted(fetch.items()):
-        if "gn_level_kernel" not in k:
+        if "gn_level_kernel" not in k and "gn_fused_kernel" not in k:
             continue
         w = write.get((k, g), 0.0)
         ff = cal["FETCH_SIZE"]["factor"] or 1.0
@@ -111,7 +114,7 @@ def main():
                                    hbm_bytes_per_launch=v * 1024.0 * ff + w * 1024.0 * wf))
     import re
     for kd in out["kernels"]:
-        m = re.search(r"gn_level_kernel\w*<(\d+)", kd["kernel"])
+        m = re.search(r"gn_(?:level|fused)_kernel\w*<(\d+)", kd["kernel"])
         kd["threads"] = int(m.group(1)) if m else None
         kd["workgroups"] = kd["grid_size"] // kd["threads"] if kd["threads"] else None
         kd["pairs"] = pairs
