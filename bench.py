@@ -67,8 +67,6 @@ def parse():
                     help="plane storage (f64 = reference-exact; arithmetic is fp64 in every mode)")
     ap.add_argument("--huber", type=float, default=0.0, help="Huber delta on every level (0 = off)")
     ap.add_argument("--bilinear", action="store_true", help="bilinear forward-additive sampling + corrected Jacobian")
-    ap.add_argument("--bilinear-gather", action="store_true",
-                    help="with --bilinear: the form that gathers every tap from global memory (A/B of the LDS-staged form)")
     ap.add_argument("--max-iterations", default=None,
                     help="diagnostic, never the default: comma list overriding the yml's max_num_iterations, level 0 first "
                          "(e.g. 0,0,1,1 = every plane streamed exactly once: the HBM-only rate of the level kernels)")
@@ -98,8 +96,7 @@ def algorithmic_bytes(level_sizes, iterations):
 
 
 KERNEL_NAMES = {"persistent": "gn_level_kernel", "fused": "gn_fused_kernel", "slide": "gn_level_kernel_slide",
-                "slide_fallback": "gn_level_kernel", "wide": "k_wide_pass1 + k_wide_pass2", "bilinear": "gn_level_kernel_bilinear",
-                "bilinear_lds": "gn_level_kernel_bilinear_lds"}
+                "slide_fallback": "gn_level_kernel", "wide": "k_wide_pass1 + k_wide_pass2", "bilinear": "gn_level_kernel_bilinear"}
 
 
 def launch_rows(launches, per_level_ms, steps, iters, level_sizes, plane_bytes, max_iter, n_pairs, storage_types):
@@ -350,8 +347,6 @@ def main():
             plane_storage=storage_code, huber_delta=[args.huber] * nl,
             sampling=native.SAMPLING_BILINEAR if args.bilinear else native.SAMPLING_NEAREST_SCATTER,
             jacobian_corrected=args.bilinear))
-    if args.bilinear_gather:
-        eng.set_bilinear_policy(-1)
     eng.set_config(cfg_fixed)
     eng.set_intrinsic_matrix(seq["K"])
     n_frames = reps * (distinct + 1)

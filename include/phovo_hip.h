@@ -233,11 +233,6 @@ int phovo_engine_set_slide_policy(phovo_engine *e, int policy);
  * that suits it alone (what a configuration without thresholds gets anyway).  PHOVO_FUSION_SPLIT: one launch per level in
  * the geometry of the fused launch -- bit-identical to PHOVO_FUSION_AUTO, for tests.  Iteration counts are the same in all
  * three; poses agree to the parity bar between AUTO and OFF (other summation order on the smaller levels). */
-/* Extension (PHOVO_SAMPLING_BILINEAR): 0 (default) stages the target frame's intensity and gradient rows in LDS wherever a
- * ring of them fits (the whole level, or a window that slides down the image; taps outside it are gathered from memory,
- * so any motion gives the same result); -1 always gathers the taps from global memory.  Same arithmetic per pixel; the two
- * forms sum in a different order (poses agree to the parity bar). */
-int phovo_engine_set_bilinear_policy(phovo_engine *e, int policy);
 enum { PHOVO_FUSION_AUTO = 0, PHOVO_FUSION_OFF = -1, PHOVO_FUSION_SPLIT = -2 };
 int phovo_engine_set_level_fusion(phovo_engine *e, int mode);
 /* 1: a pair's result does not depend on how many other pairs are aligned with it -- every batch, whatever its size,
@@ -347,13 +342,11 @@ enum { PHOVO_LAUNCH_PERSISTENT = 0,       /* gn_level_kernel: one level, one wor
        PHOVO_LAUNCH_SLIDE = 2,            /* gn_level_kernel_slide: owner ring in LDS */
        PHOVO_LAUNCH_SLIDE_FALLBACK = 3,   /* gn_level_kernel on the pairs the sliding-window launch handed over */
        PHOVO_LAUNCH_WIDE = 4,             /* k_wide_pass1 / k_wide_pass2 per iteration, many workgroups per pair */
-       PHOVO_LAUNCH_BILINEAR = 5,         /* gn_level_kernel_bilinear (extension): taps gathered from global memory */
-       PHOVO_LAUNCH_BILINEAR_LDS = 6 };   /* gn_level_kernel_bilinear_lds (extension): target rows staged in LDS */
+       PHOVO_LAUNCH_BILINEAR = 5 };       /* gn_level_kernel_bilinear (extension) */
 typedef struct phovo_launch_record {
   int level_first, level_last;            /* pyramid levels the launch covers (level_first >= level_last) */
   int kind;                               /* PHOVO_LAUNCH_* */
-  int threads, lds_bytes, workgroups;     /* launch geometry (workgroups: grid size; PHOVO_LAUNCH_BILINEAR_LDS: lds_bytes
-                                           * holds the rows of the ring instead) */
+  int threads, lds_bytes, workgroups;     /* launch geometry (workgroups: grid size) */
 } phovo_launch_record;
 /* count receives the number of launches; up to `capacity` of them are written to out (may be NULL). */
 int phovo_engine_last_launches(const phovo_engine *e, phovo_launch_record *out, int capacity, int *count);

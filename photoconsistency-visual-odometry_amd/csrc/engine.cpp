@@ -120,7 +120,6 @@ struct phovo_engine {
   int fusion = PHOVO_FUSION_AUTO;              // consecutive levels in one launch (phovo_engine_set_level_fusion)
   int cu_count = 256;
   int wide_policy = 0;                         // 0 auto, 1 always (where possible), -1 never
-  int bilinear_policy = 0;                     // 0 auto (LDS-staged form where the level's rows fit a ring), -1 gather form only
   bool batch_invariant = false;                // every batch takes the same kernels and geometries (phovo_engine_set_batch_invariant)
 };
 
@@ -469,7 +468,6 @@ int phovo_engine_create(int device, phovo_engine **out)
   }
   if (he == hipSuccess) he = gn_prepare_kernels();
   if (he == hipSuccess) he = gn_prepare_slide_kernels();
-  if (he == hipSuccess) he = gn_prepare_bilinear_kernels();
   if (he == hipSuccess) {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) e->cu_count = cus;
@@ -608,14 +606,6 @@ int phovo_engine_set_slide_policy(phovo_engine *e, int policy)
   if (!e) return fail(PHOVO_E_INVALID_ARGUMENT, "set_slide_policy: null");
   if (policy < -1 || policy > 0) return fail(PHOVO_E_INVALID_ARGUMENT, "set_slide_policy: policy must be -1 or 0");
   e->slide_policy = policy;
-  return PHOVO_OK;
-}
-
-int phovo_engine_set_bilinear_policy(phovo_engine *e, int policy)
-{
-  if (!e) return fail(PHOVO_E_INVALID_ARGUMENT, "set_bilinear_policy: null");
-  if (policy < -1 || policy > 0) return fail(PHOVO_E_INVALID_ARGUMENT, "set_bilinear_policy: policy must be -1 or 0");
-  e->bilinear_policy = policy;
   return PHOVO_OK;
 }
 
@@ -1131,16 +1121,8 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
     }
 
     if (e->ext.sampling == PHOVO_SAMPLING_BILINEAR) {
-      // the target's planes staged in LDS where a ring of its rows fits (the whole level, or a sliding window); gathered
-      // from global memory otherwise
-      const int ring = e->bilinear_policy < 0 ? 0 : gn_bilinear_ring_rows(lv.w, lv.h, e->ext.plane_storage);
-      if (ring > 0) {
-        PHOVO_HIP_CHECK(gn_launch_level_bilinear_lds(a, e->ext.plane_storage, e->ext.jacobian_corrected != 0, e->cu_count, s.stream));
-        record(l, l, PHOVO_LAUNCH_BILINEAR_LDS, 768, ring, persistent_grid(1));
-      } else {
-        PHOVO_HIP_CHECK(gn_launch_level_bilinear(a, e->ext.plane_storage, e->ext.jacobian_corrected != 0, e->cu_count, s.stream));
-        record(l, l, PHOVO_LAUNCH_BILINEAR, 256, 0, persistent_grid(gn_bilinear_wgs_per_cu()));
-      }
+      PHOVO_HIP_CHECK(gn_launch_level_bilinear(a, e->ext.plane_storage, e->ext.jacobian_corrected != 0, e->cu_count, s.stream));
+      record(l, l, PHOVO_LAUNCH_BILINEAR, 256, 0, persistent_grid(gn_bilinear_wgs_per_cu()));
     } else if (use_wide_level(e, n_pairs, lv.n) && !(e->ext.huber_delta[l] > 0.0)) {
       if (s.owner_tagged) {            // the wide form starts from -1 everywhere and leaves it so
         PHOVO_HIP_CHECK(fill_i32(s.d_owner, s.owner_capacity, -1, s.stream));

@@ -92,12 +92,6 @@ hipError_t gn_launch_fused(const GNFusedArgs &args, int storage, int cu_count, h
 hipError_t gn_launch_level_bilinear(const GNLevelArgs &args, int storage, bool corrected, int cu_count,
                                     hipStream_t stream);
 int gn_bilinear_wgs_per_cu();      // workgroups of the bilinear kernel that stay resident per CU
-// ... with the target's planes staged in LDS (1024 threads, one workgroup per CU): rows the ring holds for a level of w x h
-// in that storage -- h when the whole level fits, a power of two for a sliding ring, 0 when the level must be gathered.
-int gn_bilinear_ring_rows(int w, int h, int storage);
-hipError_t gn_prepare_bilinear_kernels();
-hipError_t gn_launch_level_bilinear_lds(const GNLevelArgs &args, int storage, bool corrected, int cu_count,
-                                        hipStream_t stream);
 // Wide form (gn_wide_kernels.hip): many workgroups per pair, three launches per iteration; for a handful of
 // pairs on large levels.  fp64 planes, reference semantics only.
 size_t gn_wide_workspace_bytes(int n, int n_pairs);

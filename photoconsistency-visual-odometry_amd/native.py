@@ -64,7 +64,7 @@ class PairReport(C.Structure):
 
 
 FUSION_AUTO, FUSION_OFF, FUSION_SPLIT = 0, -1, -2
-LAUNCH_KINDS = ("persistent", "fused", "slide", "slide_fallback", "wide", "bilinear", "bilinear_lds")
+LAUNCH_KINDS = ("persistent", "fused", "slide", "slide_fallback", "wide", "bilinear")
 
 
 class LaunchRecord(C.Structure):
@@ -119,7 +119,6 @@ SYMBOLS = {
     "phovo_engine_set_build_all_levels": (C.c_int, [_vp, C.c_int]),
     "phovo_engine_set_wide_policy": (C.c_int, [_vp, C.c_int]),
     "phovo_engine_set_level_fusion": (C.c_int, [_vp, C.c_int]),
-    "phovo_engine_set_bilinear_policy": (C.c_int, [_vp, C.c_int]),
     "phovo_engine_set_batch_invariant": (C.c_int, [_vp, C.c_int]),
     "phovo_engine_set_slide_policy": (C.c_int, [_vp, C.c_int]),
     "phovo_engine_level_uses_wide": (C.c_int, [_vp, C.c_int, C.c_int]),

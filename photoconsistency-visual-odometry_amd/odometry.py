@@ -206,10 +206,6 @@ class AlignmentEngine:
         """0 automatic, 1 wide form wherever possible, -1 persistent form only."""
         check(self._lib.phovo_engine_set_wide_policy(self._h, int(policy)), "phovo_engine_set_wide_policy")
 
-    def set_bilinear_policy(self, policy):
-        """Extension (bilinear sampling): 0 automatic (target rows staged in LDS where a ring of them fits), -1 gather form only."""
-        check(self._lib.phovo_engine_set_bilinear_policy(self._h, int(policy)), "phovo_engine_set_bilinear_policy")
-
     def set_level_fusion(self, mode):
         """native.FUSION_AUTO (default): consecutive levels that fit the 512-thread scatter kernel are ONE launch when a
         gradient threshold makes their iteration counts data-dependent; FUSION_OFF: one launch per level; FUSION_SPLIT: one

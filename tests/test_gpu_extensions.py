@@ -146,22 +146,18 @@ def test_config5_shape_huber_fp16_through_yml_and_class_surface(tmp_path):
     assert se3.state_distance(s, es) < POSE_TOL
 
 
-@pytest.mark.parametrize("policy", [0, -1])
 @pytest.mark.parametrize("corrected,storage,huber", [
     (False, native.STORAGE_F64, None),
     (True, native.STORAGE_F64, None),
     (True, native.STORAGE_F32, None),
     (True, native.STORAGE_F16, [0.0, 0.0, 0.05, 0.05]),
 ])
-def test_bilinear_sampling_matches_extended_oracle(corrected, storage, huber, policy):
-    """PHOVO_SAMPLING_BILINEAR (single-pass kernels, no owner map) against the oracle's bilinear mode, alone and
-    combined with the corrected Jacobian, narrow storages and Huber weights -- in both forms: the target's rows staged in
-    LDS (policy 0: 80x60 resident, 160x120 a sliding ring with fp64 / fp32 planes and resident with fp16) and every tap
-    gathered from global memory (policy -1)."""
+def test_bilinear_sampling_matches_extended_oracle(corrected, storage, huber):
+    """PHOVO_SAMPLING_BILINEAR (single-pass kernel, no owner map) against the oracle's bilinear mode, alone and
+    combined with the corrected Jacobian, narrow storages and Huber weights."""
     p = synthetic.make_pair(24, 640, 480, holes=0.02)
     ncfg, ocfg, nl, mi = _cfg_pair("config_4_level_optimization_analytic.yml", fixed_cap=10)
     with odometry.AlignmentEngine() as eng:
-        eng.set_bilinear_policy(policy)
         eng.set_config(ncfg)
         eng.set_extensions(native.make_extensions(plane_storage=storage, huber_delta=huber,
                                                   sampling=native.SAMPLING_BILINEAR, jacobian_corrected=corrected))
@@ -171,8 +167,7 @@ def test_bilinear_sampling_matches_extended_oracle(corrected, storage, huber, po
         eng.upload_frame(1, p["gray1"], p["depth1"])
         planes = _stored_planes(eng, 0, 1, nl, mi, 640, 480)
         s, reps = eng.align_pairs([0, 0], [1, 1], want_reports=True)
-        kinds = [r["kind"] for r in eng.last_launches()]
-        assert kinds == (["bilinear_lds"] * 2 if policy == 0 else ["bilinear"] * 2), kinds
+        assert [r["kind"] for r in eng.last_launches()] == ["bilinear"] * 2
     es, eits, etr = oracle.optimize(ocfg, p["K"], *planes, want_trace=True, huber_delta=huber,
                                     bilinear=True, corrected=corrected)
     assert list(reps[0].iterations[:nl]) == eits
@@ -183,42 +178,6 @@ def test_bilinear_sampling_matches_extended_oracle(corrected, storage, huber, po
     g_last = np.linalg.norm(etr[-1]["gradient"])
     g_scale = max(np.linalg.norm(e["gradient"]) for e in etr)
     assert abs(reps[0].gradient_norm - g_last) <= 1e-8 * max(1.0, g_scale)
-
-
-@pytest.mark.parametrize("storage", [native.STORAGE_F64, native.STORAGE_F16])
-def test_bilinear_ring_hands_large_motions_to_the_gather_path(storage):
-    """The sliding ring of the LDS-staged form holds about +-8 rows around the rows a block of source pixels comes from
-    (160x120, fp64 planes: 32 rows); a tap that falls outside is gathered from global memory instead, lane by lane, so ANY
-    motion gives the result of the gather form.  Initial states with an in-plane rotation of 0.2 rad and a vertical shift
-    (targets 10-30 rows away from their sources), a small one and zero, mixed in one batch of 300 pairs: the LDS form, the
-    gather form and the oracle agree (iteration counts, poses), and copies of a problem are bit-identical."""
-    p = synthetic.make_pair(26, 640, 480, holes=0.02)
-    nl, mi = 4, [0, 0, 4, 6]
-    ncfg = native.make_config(num_levels=nl, max_iter=mi, min_grad=[0.0] * nl)
-    ocfg = oracle.make_config(num_levels=nl, max_iter=mi, min_grad=[0.0] * nl)
-    inits = np.array([[0.0, 0.0, 0.0, 0.0, 0.0, 0.0],
-                      [0.02, -0.3, 0.0, 0.2, 0.0, 0.0],            # yaw 0.2 rad + 30 cm down: far outside the ring
-                      [0.0, 0.05, 0.0, -0.03, 0.0, 0.0]])
-    init = np.stack([inits[k % 3] for k in range(300)])
-    out = {}
-    with odometry.AlignmentEngine() as eng:
-        eng.set_config(ncfg)
-        eng.set_extensions(native.make_extensions(plane_storage=storage, sampling=native.SAMPLING_BILINEAR, jacobian_corrected=True))
-        eng.set_intrinsic_matrix(p["K"])
-        eng.reserve_frames(2, 640, 480)
-        eng.upload_frame(0, p["gray0"], p["depth0"])
-        eng.upload_frame(1, p["gray1"], p["depth1"])
-        planes = _stored_planes(eng, 0, 1, nl, mi, 640, 480)
-        for policy in (0, -1):
-            eng.set_bilinear_policy(policy)
-            out[policy] = eng.align_pairs([0] * 300, [1] * 300, init_states=init, want_reports=True)
-    for i in range(3):
-        es, eits = oracle.optimize(ocfg, p["K"], *planes, init_state=inits[i], bilinear=True, corrected=True)
-        for policy in (0, -1):
-            s, reps = out[policy]
-            assert list(reps[i].iterations[:nl]) == eits, (policy, i)
-            assert se3.state_distance(s[i], es) < POSE_TOL, (policy, i, se3.state_distance(s[i], es))
-            assert all(np.array_equal(s[k], s[i]) for k in range(i, 300, 3)), (policy, i)
 
 
 def test_bilinear_handles_levels_of_any_size_and_rejects_bad_combinations():
