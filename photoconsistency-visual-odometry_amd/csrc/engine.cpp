@@ -80,6 +80,8 @@ struct AlignSlot {
   int *d_handover = nullptr;                   // [PHOVO_MAX_LEVELS][pairs + 2] hand-over lists: sliding-window kernel -> exact kernel (view into d_pairs)
   int *d_owner = nullptr;                      // owner maps in HBM (levels whose map exceeds LDS; the wide form)
   size_t owner_capacity = 0;
+  unsigned long long *d_mask = nullptr;        // in-bounds ballots in HBM (levels whose ballots do not fit LDS next to the rest)
+  size_t mask_capacity = 0;
   bool owner_tagged = false;                   // d_owner holds tagged entries of the persistent kernel, not the -1 the wide form expects
   void *d_wide_ws = nullptr;                   // workspace of the wide (many-workgroups-per-pair) level form
   size_t wide_ws_capacity = 0;
@@ -159,8 +161,10 @@ void free_slot(AlignSlot &s)
 {
   free_pairs(s);
   if (s.d_owner) (void)hipFree(s.d_owner);
+  if (s.d_mask) (void)hipFree(s.d_mask);
   if (s.d_wide_ws) (void)hipFree(s.d_wide_ws);
   s.d_owner = nullptr; s.owner_capacity = 0; s.d_wide_ws = nullptr; s.wide_ws_capacity = 0;
+  s.d_mask = nullptr; s.mask_capacity = 0;
 }
 
 // Every enqueue in flight has finished when this returns (host wait).  Called by whatever changes device state that a
@@ -978,7 +982,7 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
   if (st != PHOVO_OK) return st;
 
   // every active level must be launchable before anything is enqueued
-  size_t owner_need = 0, wide_need = 0;
+  size_t owner_need = 0, wide_need = 0, mask_need = 0;
   for (int l = 0; l < e->cfg.num_levels; l++) {
     if (e->cfg.max_num_iterations[l] <= 0) continue;
     const LevelPool &lv = e->levels[l];
@@ -989,10 +993,16 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
       const size_t ws = gn_wide_workspace_bytes(lv.n, n_pairs);
       if (ws > wide_need) wide_need = ws;
     }
-    if (!wide && !lv.plan_ok) return fail(PHOVO_E_SHAPE, "align: pyramid level too large for the device path (in-bounds mask exceeds LDS)");
+    if (!wide && !lv.plan_ok)
+      return fail(PHOVO_E_SHAPE, "align: pyramid level too large for the device path (more than 2 097 151 pixels: the owner map in "
+                                 "HBM holds 21-bit source indices); up to 32 pairs at a time take the wide form, which has no such limit");
     if (wide || !lv.plan.owner_in_lds) {
       const size_t need = (size_t)n_pairs * (size_t)lv.n;
       if (need > owner_need) owner_need = need;
+    }
+    if (!wide && lv.plan.mask_in_hbm) {
+      const size_t need = (size_t)n_pairs * (size_t)((lv.n + 63) / 64);
+      if (need > mask_need) mask_need = need;
     }
   }
   if (owner_need > s.owner_capacity) {
@@ -1004,6 +1014,11 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
     PHOVO_HIP_CHECK(fill_i32(s.d_owner, owner_need, -1, s.stream));
   }
 
+  if (mask_need > s.mask_capacity) {
+    if (s.d_mask) { (void)hipFree(s.d_mask); s.d_mask = nullptr; s.mask_capacity = 0; }
+    PHOVO_HIP_CHECK(hipMalloc(&s.d_mask, sizeof(unsigned long long) * mask_need));
+    s.mask_capacity = mask_need;
+  }
   if (wide_need > s.wide_ws_capacity) {
     if (s.d_wide_ws) { PHOVO_HIP_CHECK(hipStreamSynchronize(s.stream)); (void)hipFree(s.d_wide_ws); s.d_wide_ws = nullptr; s.wide_ws_capacity = 0; }
     PHOVO_HIP_CHECK(hipMalloc(&s.d_wide_ws, wide_need));
@@ -1134,6 +1149,7 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
       const bool few = few_batch && lv.plan_few_ok && lv.plan_few.owner_in_lds == lv.plan.owner_in_lds;
       const GNLaunchPlan &pl = few ? lv.plan_few : lv.plan;
       a.n_lds = pl.owner_in_lds ? 0 : pl.owner_lds_entries;
+      a.g_mask = pl.mask_in_hbm ? s.d_mask : nullptr;
       int *list0 = s.d_handover + (size_t)l * lay.handover_stride;
       int *heads1 = s.d_work_counters + (PHOVO_MAX_LEVELS + l) * QUEUE_HEADS_INTS;
       if (!pl.owner_in_lds && e->slide_policy >= 0) {

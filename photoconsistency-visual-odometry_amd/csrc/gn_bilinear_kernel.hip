@@ -48,11 +48,11 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel_bilinear(const GNLevel
   if (pair >= A.n_pairs) break;
   const unsigned char *src_frame = A.planes + (size_t)A.src[pair] * A.frame_bytes;
   const unsigned char *tgt_frame = A.planes + (size_t)A.tgt[pair] * A.frame_bytes;
-  // one descriptor per frame, the plane chosen by a scalar offset (gn_device.hpp, plane_load): eight scalar registers
-  // instead of twenty
-  const __amdgpu_buffer_rsrc_t rS = frame_rsrc(src_frame, A.frame_bytes), rT = frame_rsrc(tgt_frame, A.frame_bytes);
-  const int oI = (int)A.plane_off[PLANE_I], oD = (int)A.plane_off[PLANE_D];
-  const int oGX = (int)A.plane_off[PLANE_GX], oGY = (int)A.plane_off[PLANE_GY];
+  const __amdgpu_buffer_rsrc_t rI0 = plane_rsrc<TI>(src_frame + A.plane_off[PLANE_I], n);
+  const __amdgpu_buffer_rsrc_t rD0 = plane_rsrc<TD>(src_frame + A.plane_off[PLANE_D], n);
+  const __amdgpu_buffer_rsrc_t rI1 = plane_rsrc<TI>(tgt_frame + A.plane_off[PLANE_I], n);
+  const __amdgpu_buffer_rsrc_t rGX = plane_rsrc<TI>(tgt_frame + A.plane_off[PLANE_GX], n);
+  const __amdgpu_buffer_rsrc_t rGY = plane_rsrc<TI>(tgt_frame + A.plane_off[PLANE_GY], n);
 
   if (wave == 0) {
     double st[6];
@@ -71,7 +71,6 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel_bilinear(const GNLevel
   const double fx = A.fx, fy = A.fy, ox = A.ox, oy = A.oy, ifx = A.ifx, ify = A.ify;
   const double min_d = A.min_depth, max_d = A.max_depth;
   const double wlim = (double)W - 0.5, hlim = (double)H - 0.5;
-  const double oxi = uniform_f64(-ox * ifx), oyi = uniform_f64(-oy * ify);
   const double huber_delta = A.huber_delta;
   const bool huber_on = huber_delta > 0.0;
   const int k0 = wave * WAVE + lane;
@@ -111,15 +110,15 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel_bilinear(const GNLevel
     };
     int k = k0;
     double cd = cd0, rd = rd0;
-    double pz_next = plane_load<TD>(rS, k, oD);                              // past the plane: 0
-    double i0_next = plane_load<TI>(rS, k, oI);
+    double pz_next = plane_load<TD>(rD0, k);                              // past the plane: 0
+    double i0_next = plane_load<TI>(rI0, k);
     auto warp = [&](Warped &w) {
       const double pz = pz_next;
       w.i0 = i0_next;
-      pz_next = plane_load<TD>(rS, k + NW * WAVE, oD);
-      i0_next = plane_load<TI>(rS, k + NW * WAVE, oI);
-      const double px = fma(cd, ifx, oxi) * pz;                           // :282  ((c - ox) * ifx as one fma)
-      const double py = fma(rd, ify, oyi) * pz;                           // :283
+      pz_next = plane_load<TD>(rD0, k + NW * WAVE);
+      i0_next = plane_load<TI>(rI0, k + NW * WAVE);
+      const double px = (cd - ox) * pz * ifx;                             // :282
+      const double py = (rd - oy) * pz * ify;                             // :283
       const double X = ((t15 * px + r01 * py) + r02 * pz) + cx;           // :291
       const double Y = ((t14 * px + r11 * py) + r12 * pz) + cyy;
       const double Zr = py * t1 + pz * t2 - px * t3;
@@ -149,9 +148,9 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel_bilinear(const GNLevel
           // edge pixel (clamp to edge): the pair is then loaded one column inside and the edge value copied over the other.
           const int cb = min(max(ic, 0), W - 2);
           const int oa = r0w + cb, ob = r1w + cb;
-          plane_load2<TI>(rT, oa, oI, w.tap[0], w.tap[1]); plane_load2<TI>(rT, ob, oI, w.tap[2], w.tap[3]);
-          plane_load2<TI>(rT, oa, oGX, w.tap[4], w.tap[5]); plane_load2<TI>(rT, ob, oGX, w.tap[6], w.tap[7]);
-          plane_load2<TI>(rT, oa, oGY, w.tap[8], w.tap[9]); plane_load2<TI>(rT, ob, oGY, w.tap[10], w.tap[11]);
+          plane_load2<TI>(rI1, oa, w.tap[0], w.tap[1]); plane_load2<TI>(rI1, ob, w.tap[2], w.tap[3]);
+          plane_load2<TI>(rGX, oa, w.tap[4], w.tap[5]); plane_load2<TI>(rGX, ob, w.tap[6], w.tap[7]);
+          plane_load2<TI>(rGY, oa, w.tap[8], w.tap[9]); plane_load2<TI>(rGY, ob, w.tap[10], w.tap[11]);
           const bool left = ic < 0, right = ic > W - 2;
           if (__builtin_amdgcn_ballot_w64(left || right)) {               // rare: a lane of the wave sits in that band
 #pragma unroll
@@ -164,12 +163,12 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel_bilinear(const GNLevel
         } else {
           const int c0i = max(ic, 0), c1i = min(ic + 1, W - 1);
           const int o00 = r0w + c0i, o01 = r0w + c1i, o10 = r1w + c0i, o11 = r1w + c1i;
-          w.tap[0] = plane_load<TI>(rT, o00, oI); w.tap[1] = plane_load<TI>(rT, o01, oI);
-          w.tap[2] = plane_load<TI>(rT, o10, oI); w.tap[3] = plane_load<TI>(rT, o11, oI);
-          w.tap[4] = plane_load<TI>(rT, o00, oGX); w.tap[5] = plane_load<TI>(rT, o01, oGX);
-          w.tap[6] = plane_load<TI>(rT, o10, oGX); w.tap[7] = plane_load<TI>(rT, o11, oGX);
-          w.tap[8] = plane_load<TI>(rT, o00, oGY); w.tap[9] = plane_load<TI>(rT, o01, oGY);
-          w.tap[10] = plane_load<TI>(rT, o10, oGY); w.tap[11] = plane_load<TI>(rT, o11, oGY);
+          w.tap[0] = plane_load<TI>(rI1, o00); w.tap[1] = plane_load<TI>(rI1, o01);
+          w.tap[2] = plane_load<TI>(rI1, o10); w.tap[3] = plane_load<TI>(rI1, o11);
+          w.tap[4] = plane_load<TI>(rGX, o00); w.tap[5] = plane_load<TI>(rGX, o01);
+          w.tap[6] = plane_load<TI>(rGX, o10); w.tap[7] = plane_load<TI>(rGX, o11);
+          w.tap[8] = plane_load<TI>(rGY, o00); w.tap[9] = plane_load<TI>(rGY, o01);
+          w.tap[10] = plane_load<TI>(rGY, o10); w.tap[11] = plane_load<TI>(rGY, o11);
         }
       }
       k += NW * WAVE;
@@ -255,7 +254,6 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel_bilinear(const GNLevel
   }
   }   // next pair
 }
-
 
 }  // namespace
 

@@ -71,7 +71,8 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
   constexpr int NW = T / WAVE;
   double *const s_cst = L.cst, *const s_state = L.state, *const s_red = L.red, *const s_i0 = L.i0;
   int *const s_ctl = L.ctl, *const s_owner = L.owner;
-  unsigned long long *const s_mask = L.mask;
+  // (ballots in global memory: written and read back by the same wave, chunk by chunk -- program order is all it needs)
+  unsigned long long *const s_mask = (!MASK_REG && A.g_mask) ? A.g_mask + (size_t)pair * (size_t)A.n_chunks : L.mask;
   const int tid = threadIdx.x;
   const int lane = tid & (WAVE - 1);
   // wave-uniform by construction; saying so lets the chunk loops run on the scalar unit (s_cmp / s_cbranch)
@@ -529,7 +530,7 @@ template <int T, int WPS, bool SRC_LDS, bool OWNER_LDS, bool MASK_REG, typename 
 __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
 {
   extern __shared__ __align__(16) unsigned char lds_raw[];
-  const LevelLds L = carve_lds<T, SRC_LDS, OWNER_LDS, MASK_REG>(lds_raw, A.n, A.n_chunks);
+  const LevelLds L = carve_lds<T, SRC_LDS, OWNER_LDS, MASK_REG>(lds_raw, A.n, A.g_mask ? 0 : A.n_chunks);
   int *const s_ctl = L.ctl;
   const int tid = threadIdx.x;
   for (int k = tid; k < (OWNER_LDS ? owner_lds_entries(A.n, T) : A.n_lds); k += T) L.owner[k] = -1;
@@ -644,6 +645,7 @@ enum Variant { V_TINY = 0, V_MID, V_WIDE, V_HUGE, V_QUAD, V_SOLO };
 bool gn_plan_level(int n, GNLaunchPlan *plan, int prefer_latency)
 {
   plan->owner_lds_entries = 0;
+  plan->mask_in_hbm = false;
   const size_t n_chunks = (size_t)(n + WAVE - 1) / WAVE;
   auto owner_bytes = [n](int threads) { return sizeof(int) * (size_t)owner_lds_entries(n, threads); };
   const size_t src = sizeof(double) * (size_t)n;
@@ -684,9 +686,12 @@ bool gn_plan_level(int n, GNLaunchPlan *plan, int prefer_latency)
     plan->lds_bytes = (int)(f1024 + owner_bytes(1024));
     return true;
   }
-  const size_t mask = sizeof(unsigned long long) * n_chunks;
-  if (f1024 + mask > LDS_LIMIT) return false;
+  size_t mask = sizeof(unsigned long long) * n_chunks;
   if (n > OWNER_INDEX_MASK) return false;          // the tagged entries of the HBM owner map hold 21-bit indices
+  if (f1024 + mask > LDS_LIMIT / 2) {              // the ballots would take most of LDS (or do not fit): global memory
+    plan->mask_in_hbm = true;
+    mask = 0;
+  }
   // whatever LDS the ballot masks leave free holds the leading part of the owner map (whole 64-pixel chunks)
   const size_t spare = LDS_LIMIT - f1024 - mask;
   plan->owner_lds_entries = tuning_switch("PHOVO_GN_NO_OWNER_SPLIT") ? 0 : (int)((spare / sizeof(int)) / WAVE * WAVE);

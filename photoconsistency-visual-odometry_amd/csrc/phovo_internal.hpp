@@ -33,6 +33,8 @@ struct GNLevelArgs {
   double *states;           // [pairs][6] in: initial / previous level, out: updated
   phovo_pair_report *reports;   // [pairs]
   int *g_owner;             // [pairs][n] owner map in global memory (only when it does not fit LDS)
+  unsigned long long *g_mask;   // [pairs][n_chunks] in-bounds ballots in global memory (only when they do not fit LDS either:
+                                // levels above ~1.27 M pixels), else null
   int n_pairs;              // pairs of this launch
   int *work_counter;        // [QUEUES_PER_LEVEL] heads QUEUE_HEAD_STRIDE ints apart, zeroed before the launch: workgroups draw pair indices from them
   int n_queues;             // 1: one queue for the whole grid; 8: one per XCD over a contiguous eighth of the pairs (+ stealing)
@@ -72,6 +74,7 @@ struct GNLaunchPlan {
   bool owner_in_lds;
   bool source_in_lds;
   int owner_lds_entries;    // owner map in HBM: how many of its leading entries the leftover LDS holds (GNLevelArgs::n_lds)
+  bool mask_in_hbm;         // owner map in HBM and a level so large that the per-chunk ballots do not fit LDS either
 };
 
 // Chooses the launch geometry for a level of n pixels.  Returns false if the level cannot be

@@ -788,6 +788,70 @@ def test_randomised_sweep_against_oracle():
     assert "80 cases, 0 failures" in r.stdout
 
 
+def test_randomised_sweep_of_thin_strips_holds_the_conditioned_bar():
+    """tests/tools/fuzz_parity.py in its `strips` mode: 120 one-level strips of 250-330 x 12-20 pixels -- the shape class in
+    which round 3's long sweeps met two cases at 1.2e-9 / 1.3e-9 (282x15, 309x15).  A dozen rows barely constrain the
+    rotation about the image's long axis: cond(J^T J) reaches 1e7 there, against 1e3-1e5 on everything else, and the two
+    sides' different summation orders come back multiplied by it.  The tool's bar is 1e-9 x max(1, cond / 1e6) -- flat 1e-9
+    for every well-conditioned case -- with cond taken from the oracle's own normal equations; iteration counts must be
+    identical as always."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "fuzz_parity.py"), "120", "3", "strips"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "120 cases, 0 failures" in r.stdout
+    m = __import__("re").search(r"largest cond\(J\^T J\) ([0-9.e+]+); (\d+) cases above 1e6 .* worst distance / bar ([0-9.]+)", r.stdout)
+    assert m, r.stdout[-500:]
+    print(r.stdout.strip().splitlines()[-3])
+
+
+def test_full_hd_level_zero_on_every_form():
+    """The reference aligns any image size (...Analytic.h:505-507).  1920x1080 with level 0 active (2 073 600 pixels: just
+    inside the 21-bit source indices of the owner map in HBM): one pair (the wide form), 40 pairs (the sliding-window kernel,
+    and for the pair with a 0.2 rad in-plane rotation its exact fall-back with the in-bounds ballots in global memory --
+    259 KB of them per pair do not fit LDS) all match the oracle; a level of more than 2 097 151 pixels is refused with
+    PHOVO_E_SHAPE for batches the wide form does not take."""
+    p = synthetic.make_pair(31, 1920, 1080, holes=0.01, trans=0.01, rot=0.004)
+    ncfg, ocfg = _cfgs(1, [2], [0.0])
+    inits = np.zeros((40, 6))
+    inits[7] = [0.0, 0.0, 0.0, 0.2, 0.0, 0.0]           # leaves the sliding window at once
+    exp = {}
+    i0p, d0p = oracle.build_source_pyramids(p["gray0"], p["depth0"], ocfg)
+    i1p, gxp, gyp = oracle.build_target_pyramids(p["gray1"], ocfg)
+    for k in (0, 7):
+        exp[k] = oracle.optimize(ocfg, p["K"], i0p, d0p, i1p, gxp, gyp, init_state=inits[k])
+    with odometry.AlignmentEngine() as eng:
+        eng.set_config(ncfg)
+        eng.set_intrinsic_matrix(p["K"])
+        eng.reserve_frames(2, 1920, 1080)
+        eng.upload_frame(0, p["gray0"], p["depth0"], roles=native.ROLE_SOURCE)
+        eng.upload_frame(1, p["gray1"], None, roles=native.ROLE_TARGET)
+        one, r1 = eng.align_pairs([0], [1], want_reports=True)
+        assert [r["kind"] for r in eng.last_launches()] == ["wide"]
+        many, rm = eng.align_pairs([0] * 40, [1] * 40, init_states=inits, want_reports=True)
+        assert [r["kind"] for r in eng.last_launches()] == ["slide", "slide_fallback"]
+    assert list(r1[0].iterations[:1]) == exp[0][1] and se3.state_distance(one[0], exp[0][0]) < POSE_TOL
+    for k in range(40):
+        es, eits = exp[7 if k == 7 else 0]
+        assert list(rm[k].iterations[:1]) == eits, k
+        assert se3.state_distance(many[k], es) < POSE_TOL, (k, se3.state_distance(many[k], es))
+    assert rm[7].flags & native.PAIR_WINDOW_FALLBACK and not rm[0].flags
+    # 2048 x 1152 = 2 359 296 pixels: beyond the 21-bit indices
+    q = synthetic.make_pair(32, 2048, 1152, trans=0.004, rot=0.002)
+    with odometry.AlignmentEngine() as eng:
+        eng.set_config(ncfg)
+        eng.set_intrinsic_matrix(q["K"])
+        eng.reserve_frames(2, 2048, 1152)
+        eng.upload_frame(0, q["gray0"], q["depth0"], roles=native.ROLE_SOURCE)
+        eng.upload_frame(1, q["gray1"], None, roles=native.ROLE_TARGET)
+        with pytest.raises(native.PhovoError) as err:
+            eng.align_pairs([0] * 40, [1] * 40)
+        assert err.value.status == native.E_SHAPE and "2 097 151" in str(err.value)
+        s, r = eng.align_pairs([0], [1], want_reports=True)          # the wide form has no such limit
+        assert np.all(np.isfinite(s)) and r[0].iterations[0] == 2
+
+
 def test_randomised_sweep_of_large_levels_against_oracle():
     """tests/tools/fuzz_parity.py in its `big` mode: 40 random problems of 240x200 ... 700x500 pixels with 1-2 levels, 40 or 300
     pairs, in-plane rotations of up to 0.25 rad -- level 0 exceeds what an owner map in LDS holds, so this sweeps the

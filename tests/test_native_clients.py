@@ -29,6 +29,40 @@ def test_header_is_valid_c_and_c_client_runs(tmp_path):
     assert "cabi_c_client ok" in r.stdout
 
 
+@pytest.mark.gpu
+def test_c_client_aligns_a_golden_pair_on_the_gpu(tmp_path):
+    """A program written in plain C drives the whole path on the device -- phovo_odometry_create ... set_source_frame,
+    set_target_frame, optimize, get_* in the reference's call order (...FrameAlignment.cpp:92-105) -- on the inputs of
+    tests/golden/case_a.npz and lands within 1e-9 of the fixture's expected state (the numpy twin's), iteration counts
+    equal."""
+    import numpy as np
+    native.lib()
+    exe = tmp_path / "cabi_c_client"
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "native", "cabi_c_client.c"), "-o", str(exe),
+                           "-L", PKG, "-lphovo_hip", "-lm", f"-Wl,-rpath,{PKG}", "-Wl,-rpath,/opt/rocm/lib"])
+    d = np.load(os.path.join(ROOT, "tests", "golden", "case_a.npz"))
+    nl = int(d["num_levels"])
+    h, w = d["gray0"].shape
+    blob = [np.array([w, h, nl], dtype=np.int32).tobytes(), np.ascontiguousarray(d["K"], dtype=np.float64).tobytes(),
+            np.array([float(d["min_depth"]), float(d["max_depth"])]).tobytes()]
+    for l in range(nl):
+        blob.append(np.array([int(d["max_iter"][l])], dtype=np.int32).tobytes())
+        blob.append(np.array([d["min_grad"][l], d["lam"][l], d["grad_scale"][l]], dtype=np.float64).tobytes())
+    blob += [np.ascontiguousarray(d["gray0"], dtype=np.uint8).tobytes(), np.ascontiguousarray(d["depth0"], dtype=np.float64).tobytes(),
+             np.ascontiguousarray(d["gray1"], dtype=np.uint8).tobytes(),
+             np.ascontiguousarray(d["init_state"], dtype=np.float64).tobytes(),
+             np.ascontiguousarray(d["exp_state"], dtype=np.float64).tobytes(),
+             np.ascontiguousarray(d["exp_iters"][:nl], dtype=np.int32).tobytes()]
+    problem = tmp_path / "case_a.bin"
+    problem.write_bytes(b"".join(blob))
+    r = subprocess.run([str(exe), os.path.join(CFG, "config_4_level_optimization_analytic.yml"), str(problem)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "gpu alignment from C" in r.stdout and "cabi_c_client ok" in r.stdout
+    print(r.stdout)
+
+
 def test_yml_reader_under_asan_ubsan(tmp_path):
     exe = tmp_path / "yml_asan"
     csrc = os.path.join(ROOT, "photoconsistency-visual-odometry_amd", "csrc")

@@ -1,9 +1,18 @@
 """Randomised device-vs-oracle sweep (run on the GPU box): odd image sizes, 1-3 levels, intrinsics that are not
 half-integers, depth holes / NaN / out-of-range depth, large motions, non-zero initial states, every launch geometry
 the sizes select, optionally narrow storage / Huber / bilinear.  Prints one line per failure and a summary; exit code 1
-if any case misses the 1e-9 pose bar or an iteration count.
+if any case misses the pose bar or an iteration count.
 
-    python tests/tools/fuzz_parity.py [cases=150] [seed=0] [ext] [big]
+The pose bar is 1e-9 x max(1, cond(J^T J) / 1e6), with cond the largest condition number of the normal equations over the
+oracle's iterations (printed with every failure and, as a maximum, in the summary).  Device and oracle sum the same terms
+in a different order, i.e. they solve normal equations that differ by ~1e-15 relative; the solve returns that times the
+condition number.  For everything the reference's configurations produce cond is 1e3 ... 1e5 and the bar is the flat 1e-9 the
+GPU tests hold; the scaling matters for degenerate shapes only -- strips of a dozen rows barely constrain the rotation
+about the image's long axis (cond ~ 1e7): round 3's sweeps met two such cases at 1.2e-9 and 1.3e-9 (282x15, 309x15).
+
+    python tests/tools/fuzz_parity.py [cases=150] [seed=0] [ext] [big] [strips]
+
+With `strips` every case is a one-level strip of 250-330 x 12-20 pixels (that shape class, on purpose).
 
 With `ext` every case also draws a combination of the opt-in extensions (fp32 / fp16 plane storage, Huber weights,
 bilinear sampling with or without the corrected Jacobian); the oracle is then fed the planes as the device stored them.
@@ -25,7 +34,20 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 with_ext = "ext" in sys.argv[3:]
 big = "big" in sys.argv[3:]
+strips = "strips" in sys.argv[3:]
 bad, worst, variants, fallbacks = 0, 0.0, {}, 0
+worst_ratio, worst_cond, ill = 0.0, 0.0, 0
+
+
+def worst_condition(trace):
+    c = 1.0
+    for e in trace:
+        h = e["hessian"]
+        if np.all(np.isfinite(h)) and np.any(h != 0.0):
+            c = max(c, float(np.linalg.cond(h)))
+    return c
+
+
 # FUZZ_ONLY=12,345: replay the random draws of every case but run only these (to look at a failure again)
 only = {int(c) for c in os.environ["FUZZ_ONLY"].split(",")} if os.environ.get("FUZZ_ONLY") else None
 for case in range(cases):
@@ -35,6 +57,9 @@ for case in range(cases):
     w = int(rs.randint(240, 700) if big else rs.randint(16, 330)) // unit * unit + (unit if rs.rand() < 0.5 else 0)
     h = int(rs.randint(200, 500) if big else rs.randint(12, 250)) // unit * unit + (unit if rs.rand() < 0.5 else 0)
     w, h = max(w, 8 * unit), max(h, 8 * unit)
+    if strips:
+        nl, unit = 1, 1
+        w, h = int(rs.randint(250, 331)), int(rs.randint(12, 21))
     kw = dict(holes=float(rs.choice([0.0, 0.02, 0.2])), trans=float(rs.choice([0.002, 0.02, 0.08])),
               rot=float(rs.choice([0.001, 0.01, 0.05, 0.25] if big else [0.001, 0.01, 0.05])))
     p = synthetic.make_pair(1000 + case, w, h, **kw) if active else dict(K=synthetic.intrinsics(w, h), depth0=np.zeros((h, w)))
@@ -74,7 +99,7 @@ for case in range(cases):
         bilinear = rs.rand() < 0.5
         corrected = bool(bilinear and rs.rand() < 0.5)
     else:
-        es, eits = oracle.align_frames(ocfg, K, p["gray0"], d0, p["gray1"], init_state=init)[:2]
+        es, eits, otrace = oracle.align_frames(ocfg, K, p["gray0"], d0, p["gray1"], init_state=init, want_trace=True)
     with odometry.AlignmentEngine() as eng:
         eng.set_config(ncfg)
         if with_ext:
@@ -97,8 +122,8 @@ for case in range(cases):
                     i0 = dd = i1 = gx = gy = np.zeros((lh, lw))
                 for lst, v in zip(planes, (i0, dd, i1, gx, gy)):
                     lst.append(v)
-            es, eits = oracle.optimize(ocfg, K, *planes, init_state=init, huber_delta=huber, bilinear=bilinear,
-                                       corrected=corrected)[:2]
+            es, eits, otrace = oracle.optimize(ocfg, K, *planes, init_state=init, huber_delta=huber, bilinear=bilinear,
+                                               corrected=corrected, want_trace=True)
         n_pairs = int(rs.choice([40, 300] if big else [1, 3, 40]))          # 40 > 32: never the wide form
         inits = None if init is None else np.tile(init, (n_pairs, 1))
         s, reps = eng.align_pairs([0] * n_pairs, [1] * n_pairs, init_states=inits, want_reports=True)
@@ -110,9 +135,13 @@ for case in range(cases):
     fallbacks += int(bool(reps[0].flags & native.PAIR_WINDOW_FALLBACK))
     its = list(reps[0].iterations[:nl])
     finite = np.all(np.isfinite(es))
+    cond = worst_condition(otrace)
+    bar = 1e-9 * max(1.0, cond / 1e6)
     if finite:
         d = se3.state_distance(s[0], es)
-        ok = its == eits and d < 1e-9 and all(np.array_equal(s[0], s[i]) for i in range(n_pairs))
+        ok = its == eits and d < bar and all(np.array_equal(s[0], s[i]) for i in range(n_pairs))
+        worst_ratio, worst_cond = max(worst_ratio, d / bar), max(worst_cond, cond)
+        ill += int(cond > 1e6)
     else:                                   # the oracle ran into NaN (no valid pixel / singular H): flagged, not hidden
         d = 0.0
         ok = bool(reps[0].flags & native.PAIR_NONFINITE) and not np.all(np.isfinite(s[0]))
@@ -120,11 +149,12 @@ for case in range(cases):
     if not ok:
         bad += 1
         print(f"FAIL case {case}: {w}x{h} levels {nl} max_iter {max_iter} min_grad {min_grad} pairs {n_pairs} "
-              f"iterations gpu {its} cpu {eits} distance {d:.3e} flags {reps[0].flags} "
+              f"iterations gpu {its} cpu {eits} distance {d:.3e} cond {cond:.2e} bar {bar:.1e} flags {reps[0].flags} "
               f"ext(storage {storage}, huber {huber}, bilinear {bilinear}, corrected {corrected})")
     if (case + 1) % 500 == 0:                 # a long sweep must not look hung to whoever is watching its output
         print(f"... {case + 1} cases so far, {bad} failures, worst {worst:.3e}", flush=True)
 print(f"{cases} cases, {bad} failures, worst pose distance {worst:.3e}")
+print(f"largest cond(J^T J) {worst_cond:.2e}; {ill} cases above 1e6 (bar scaled); worst distance / bar {worst_ratio:.3f}")
 print(f"pairs finished by the exact kernel after leaving the sliding window: {fallbacks} cases")
 print("launch geometries exercised (threads, owner in LDS, source in LDS, wide form): ", variants)
 sys.exit(1 if bad else 0)
