@@ -52,14 +52,14 @@ typedef enum phovo_status {
                                     the sliding window of the fast kernel (a displacement of more than ~12 000 pixels in
                                     linear index, e.g. a large in-plane rotation) and the exact kernel with the map
                                     in HBM finished it.  The result is the same; only the time differs.          */
+#define PHOVO_PAIR_RANK_DEFICIENT 4u  /* fewer than six Jacobian rows were filled in SOME iteration of some level (the
+                                    flag is sticky; phovo_pair_report.valid_pixels holds the count of each level's last
+                                    iteration): J^T J was singular by construction there and the step taken from it
+                                    rounding noise -- finite or not -- exactly as in the reference, which inverts such a
+                                    matrix without a word (...Analytic.h:540).                                        */
 
 /* The per-level parameter vectors of the reference (...Analytic.h:91-103), as filled by
  * ReadConfigurationFile (:581-607) or by the constructor defaults (:430-443). */
-#define PHOVO_PAIR_RANK_DEFICIENT 4u  /* fewer than six Jacobian rows were filled in the last iteration of some level
-                                    (phovo_pair_report.valid_pixels): J^T J is singular by construction and the step taken
-                                    from it is rounding noise -- finite or not -- exactly as in the reference, which
-                                    inverts such a matrix without a word (...Analytic.h:540).                        */
-
 typedef struct phovo_config {
   int    num_levels;                                       /* numOptimizationLevels                      */
   int    blur_filter_size[PHOVO_MAX_LEVELS];               /* blurFilterSize (at each level)             */

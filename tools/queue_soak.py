@@ -1,10 +1,11 @@
 """Soak test of the work queue's pair hand-over: N launches of 2500 shuffled copies of three problems (5-level
 configuration, 5 fixed iterations per active level); every copy of a problem must come out bit-identical in every launch.
-    python tools/queue_soak.py [launches=500] [fixed|shipped|layered|slide]
-`layered` is `shipped` on problems of the layered scene (most pairs are handed over: the long pairs' chain carries the
-batch); `shipped` keeps the yml's thresholds instead (data-dependent termination: the capped two- / three-launch levels and their
-hand-over lists); `slide` soaks the sliding-window kernel (320x240, one level, 6 fixed iterations, a problem with a 0.3 rad
-in-plane rotation among them, i.e. its hand-over to the exact kernel too).
+    python tools/queue_soak.py [launches=500] [fixed|shipped|layered|pipelined|slide]
+`shipped` keeps the yml's thresholds instead (data-dependent termination: 80x60 and 160x120 are ONE fused launch in which a
+pair flows through both levels, gn_fused_kernel); `layered` is `shipped` on problems of the layered scene (most pairs run
+long); `pipelined` is `shipped` with two enqueues in flight at a time (tickets, phovo_hip.h "Pipelining"); `slide` soaks the
+sliding-window kernel (320x240, one level, 6 fixed iterations, a problem with a 0.3 rad in-plane rotation among them, i.e.
+its hand-over to the exact kernel too).
 Before the explicit LDS wait in front of the loop-head barrier about one launch in ten failed."""
 import os
 import sys
@@ -58,10 +59,19 @@ with odometry.AlignmentEngine() as eng:
     for i in range(3):
         idx = np.where(order == i)[0]
         assert all(np.array_equal(ref[idx[0]], ref[k]) for k in idx), "first launch already inconsistent"
+    pending = None
     for t in range(launches):
-        s = eng.align_pairs(src, tgt, init_states=init)
+        if mode == "pipelined":          # launch t is issued before launch t - 1 is fetched
+            eng.enqueue_align(src, tgt, init_states=init)
+            ticket = eng.last_ticket()
+            s = eng.fetch(pending, len(src)) if pending is not None else ref
+            pending = ticket
+        else:
+            s = eng.align_pairs(src, tgt, init_states=init)
         if not np.array_equal(s, ref):
             bad += 1
             print(f"launch {t}: {int((s != ref).any(axis=1).sum())} pairs differ")
+    if pending is not None and not np.array_equal(eng.fetch(pending, len(src)), ref):
+        bad += 1
 print(f"{mode}: {launches} launches of 2500 pairs, {bad} with deviations")
 sys.exit(1 if bad else 0)
