@@ -442,7 +442,7 @@ def main():
         eng.set_config(cfg_ref)
         run_steps(eng, src, tgt, 1, use_dist, device, n_global)
         barrier()
-        k2 = max(2, args.steps // 2)
+        k2 = max(2, args.steps)
         wall2, lv2 = run_steps(eng, src, tgt, k2, use_dist, device, n_global)           # one enqueue at a time: event spans
         barrier()
         wall2_serial = wall2

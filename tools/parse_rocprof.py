@@ -77,6 +77,50 @@ def sq_summary(rows, pairs):
     return out
 
 
+def launch_table(bench, stats_csv, traffic, sq, path):
+    """<tag>_launches.json: every launch of one step as bench.py recorded it (levels, kernel, algorithmic bytes from the
+    iteration counts the pairs reported) with the rocprofv3 average duration of that kernel (kernel trace of the same
+    command), its HBM-side traffic and vector-unit share (separate --pmc passes), and the fraction of the 8 TB/s roofline.
+    `whole_step` takes the un-profiled HIP-event span of bench.py (first launch to last) for the same bytes."""
+    import re
+    ns = {r["Name"]: (float(r["AverageNs"]), int(r["Calls"])) for r in csv.DictReader(open(stats_csv))} if os.path.exists(stats_csv) else {}
+    rows = []
+    for l in bench["roofline"]["launches"]:
+        fam, threads, types = re.match(r"([\w +]+)<(\d+), \.\.\. (.*)>", l["kernel"]).groups()
+
+        def same(name):
+            m = re.search(r"(\w+)<(\d+),", name)
+            return bool(m) and m.group(1) == fam and int(m.group(2)) == int(threads) and types in name
+        row = dict(levels=l["levels"], kernel=l["kernel"], workgroups=l["workgroups"], algorithmic_bytes=l["algorithmic_bytes"],
+                   iterations_per_pair=l["iterations_per_pair"], bench_event_ms=l["avg_launch_ms"])
+        shared = sum(1 for o in bench["roofline"]["launches"] if o["kernel"] == l["kernel"])
+        for name, (avg, calls) in ns.items():
+            if same(name) and shared == 1:
+                row.update(rocprof_avg_us=avg / 1e3, rocprof_calls=calls,
+                           frac_of_8TBs=l["algorithmic_bytes"] / (avg * 1e-9) / 8e12)
+            elif same(name):     # one instantiation, several launches per step (levels): the trace's average mixes them
+                row.update(rocprof_avg_us_over_its_launches=avg / 1e3, rocprof_calls=calls,
+                           frac_of_8TBs=l["algorithmic_bytes"] / (l["avg_launch_ms"] * 1e-3) / 8e12,
+                           frac_from="bench.py's HIP-event span of this launch")
+        for kd in traffic.get("kernels", []):
+            if same(kd["kernel"]) and shared == 1:
+                row.update(hbm_bytes_per_launch=kd["hbm_bytes_per_launch"],
+                           traffic_over_algorithmic=kd["hbm_bytes_per_launch"] / l["algorithmic_bytes"])
+        for kd in sq or []:
+            if same(kd["kernel"]) and "simd_valu_busy" in kd:
+                row.update(simd_valu_busy=kd["simd_valu_busy"], parked_share=kd["fraction_of_wave_cycles"]["parked (SQ_WAIT_ANY: s_waitcnt / barrier)"],
+                           valu_instructions_per_launch=kd["counters"].get("SQ_INSTS_VALU"))
+        rows.append(row)
+    total = sum(r["algorithmic_bytes"] for r in rows)
+    out = dict(command=bench["config"]["workload"], pairs=bench["config"]["pairs_per_gpu"], launches=rows,
+               whole_step=dict(algorithmic_bytes=total, bench_value=bench["value"], pipelined=bench.get("pipelined"),
+                               all_launches_frac=bench["roofline"]["all_levels_frac"],
+                               throughput_frac=total * bench["value"] / bench["config"]["pairs_per_gpu"] / 8e12,
+                               one_enqueue_at_a_time=bench.get("one_enqueue_at_a_time")))
+    json.dump(out, open(path, "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
 def main():
     src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
     pairs = int(sys.argv[sys.argv.index("--pairs") + 1]) if "--pairs" in sys.argv else 8192
@@ -123,6 +167,9 @@ def main():
     if sq:
         json.dump(dict(tag=tag, kernels=sq), open(os.path.join(dst, f"{tag}_pmc_sq.json"), "w"), indent=1)
         print(json.dumps(sq, indent=1))
+    if "--bench" in sys.argv:        # per-launch table: bench.py's own launch rows joined with the trace and the counters
+        launch_table(json.loads(open(sys.argv[sys.argv.index("--bench") + 1]).read().strip().splitlines()[-1]),
+                     os.path.join(dst, f"{tag}_kernel_stats.csv"), out, sq, os.path.join(dst, f"{tag}_launches.json"))
     if "--current" in sys.argv:      # the file bench.py reads for roofline.traffic
         json.dump(out, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
