@@ -167,7 +167,7 @@ def profile_context(kernel, pairs):
                             GBs=kd["hbm_bytes_per_launch"] / ns[kd["kernel"]],
                             source=f"profiles/{tag}_stream_once_*: this kernel with one iteration per pair (every plane read "
                                    "exactly once per launch: pure HBM); the timed run's traffic above that rate is "
-                                   "Infinity-Cache hits (DESIGN.md 5.0)")
+                                   "Infinity-Cache hits (DESIGN.md 5.2)")
             except Exception:
                 pass
     return out
