@@ -791,17 +791,17 @@ def test_randomised_sweep_against_oracle():
 def test_randomised_sweep_of_thin_strips_holds_the_conditioned_bar():
     """tests/tools/fuzz_parity.py in its `strips` mode: 120 one-level strips of 250-330 x 12-20 pixels -- the shape class in
     which round 3's long sweeps met two cases at 1.2e-9 / 1.3e-9 (282x15, 309x15).  A dozen rows barely constrain the
-    rotation about the image's long axis: cond(J^T J) reaches 1e7 there, against 1e3-1e5 on everything else, and the two
-    sides' different summation orders come back multiplied by it.  The tool's bar is 1e-9 x max(1, cond / 1e6) -- flat 1e-9
-    for every well-conditioned case -- with cond taken from the oracle's own normal equations; iteration counts must be
-    identical as always."""
+    rotation about the image's long axis: cond(J^T J) reaches 1e6-1e8 there, against 1e2-1e3 for the reference's
+    configurations on 640x480 pyramids, and the two sides' different summation orders come back multiplied by it.  The
+    tool's bar is 1e-9 x max(1, cond / 1e5) -- flat 1e-9 for every well-conditioned case -- with cond taken from the
+    oracle's own normal equations; iteration counts must be identical as always."""
     import subprocess
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "fuzz_parity.py"), "120", "3", "strips"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "120 cases, 0 failures" in r.stdout
-    m = __import__("re").search(r"largest cond\(J\^T J\) ([0-9.e+]+); (\d+) cases above 1e6 .* worst distance / bar ([0-9.]+)", r.stdout)
+    m = __import__("re").search(r"largest cond\(J\^T J\) ([0-9.e+]+); (\d+) cases above 1e5 .* worst distance / bar ([0-9.]+)", r.stdout)
     assert m, r.stdout[-500:]
     print(r.stdout.strip().splitlines()[-3])
 
