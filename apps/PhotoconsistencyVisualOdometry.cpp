@@ -1,7 +1,7 @@
 // PhotoconsistencyVisualOdometry on the MI355X path: frame-to-frame odometry over a TUM-format RGB-D
 // directory, writing a TUM trajectory file.
 //
-//   ./PhotoconsistencyVisualOdometry <config_file.yml> <rgbd_dataset_directory> <output_trajectory_file> [--batch [--gpus N]]
+//   ./PhotoconsistencyVisualOdometry <config_file.yml> <rgbd_dataset_directory> <output_trajectory_file> [--batch [--gpus N] [--rccl]]
 //
 // Behaviour kept from the reference's app (apps/PhotoconsistencyVisualOdometry/PhotoconsistencyVisualOdometry.cpp):
 //   * <dir>/rgb.txt and <dir>/depth.txt are read in lock step -- line n of one is paired with line n of the
@@ -15,8 +15,9 @@
 // `Time = ... sec.` and `Rt:` for each.  --batch loads the whole sequence, builds every pyramid once on the
 // GPU (the reference builds each frame's pyramids twice, :222-223) and aligns all pairs in one batched call;
 // the trajectory is identical.  --batch --gpus N cuts the pairs into N contiguous ranges, one engine and one host thread
-// per device (single process: the results meet in host memory, no collective); the trajectory file is the same for
-// every N.  The one-process-per-GPU form with the RCCL all_gather is apps/PhotoconsistencyVisualOdometrySharded.py.
+// per device (single process: the results meet in host memory; with --rccl through ONE RCCL all_gather from the engines'
+// device buffers, apps/rccl/rccl_gather.cpp); the trajectory file is the same for every N and either way.  The
+// one-process-per-GPU form with the RCCL all_gather is apps/PhotoconsistencyVisualOdometrySharded.py.
 #include <sys/stat.h>
 
 #include <algorithm>
@@ -33,6 +34,7 @@
 #include <vector>
 
 #include "io/png_io.h"
+#include "rccl/rccl_gather.h"
 #include "phovo/CPhotoconsistencyOdometryAnalytic.h"
 
 typedef double CoordinateType;
@@ -100,7 +102,7 @@ static bool writePose(std::ofstream &f, double timestamp, const Matrix44Type &po
 static void printHelp()
 {
   std::cout << "./PhotoconsistencyVisualOdometry <config_file.yml> <rgbd_dataset_directory> "
-               "<output_trajectory_file> [--batch [--gpus N]]" << std::endl;
+               "<output_trajectory_file> [--batch [--gpus N] [--rccl]]" << std::endl;
 }
 
 #define PHOVO_OK_OR_FAIL(call)                                                              \
@@ -112,13 +114,16 @@ int main(int argc, char *argv[])
   const std::string configFile(argv[1]), datasetDir(argv[2]), trajectoryPath(argv[3]);
   bool batch = false;
   int nGpus = 1;                                      // --batch --gpus N: the pairs of the sequence sharded over N devices
+  bool rccl = false;                                  // ... --rccl: the shards' states meet through ONE RCCL all_gather
   for (int i = 4; i < argc; i++) {
     const std::string a(argv[i]);
     if (a == "--batch") batch = true;
+    else if (a == "--rccl") rccl = true;
     else if (a == "--gpus" && i + 1 < argc) nGpus = std::atoi(argv[++i]);
     else { printHelp(); return EXIT_FAILURE; }
   }
   if (nGpus < 1 || (nGpus > 1 && !batch)) { std::cerr << "--gpus N needs --batch and N >= 1" << std::endl; return EXIT_FAILURE; }
+  if (rccl && !batch) { std::cerr << "--rccl needs --batch" << std::endl; return EXIT_FAILURE; }
   if (!fileExists(configFile)) { std::cerr << "Input config file " << configFile << " does not exist" << std::endl; return EXIT_FAILURE; }
   if (!fileExists(datasetDir)) { std::cerr << "Input RGBD dataset directory " << datasetDir << " does not exist" << std::endl; return EXIT_FAILURE; }
   const std::string rgbList = datasetDir + "/rgb.txt", depthList = datasetDir + "/depth.txt";
@@ -244,6 +249,17 @@ int main(int argc, char *argv[])
       const int nPairs = (int)nFrames - 1;
       std::vector<double> states((size_t)nPairs * 6);
       std::vector<std::string> shardError(nGpus);
+      // --rccl: instead of every shard copying its states to the host itself, the shards' device buffers meet in ONE RCCL
+      // all_gather (one communicator and one host thread per device in this one process) and rank 0 copies the lot out --
+      // the collective of SURVEY.md section 8e, with the host side staying C++.  Same bytes in the trajectory file.
+      phovo_rccl::Group group;
+      const int maxShard = nPairs / nGpus + (nPairs % nGpus ? 1 : 0);
+      if (rccl) {
+        std::vector<int> devices(nGpus);
+        for (int g = 0; g < nGpus; g++) devices[g] = g % nDevices;
+        std::string err;
+        if (!group.create(devices, &err)) { std::cerr << err << std::endl; return EXIT_FAILURE; }
+      }
       const auto t0 = std::chrono::steady_clock::now();
       auto alignShard = [&](int g) {
         const int base = nPairs / nGpus, extra = nPairs % nGpus;
@@ -264,8 +280,17 @@ int main(int argc, char *argv[])
           return fail("phovo_engine_upload_frames_u16");
         std::vector<int> src(b - a), tgt(b - a);
         for (int p = 0; p < b - a; p++) { src[p] = p; tgt[p] = p + 1; }
-        if (phovo_engine_align_pairs(engine, b - a, src.data(), tgt.data(), nullptr, states.data() + (size_t)a * 6, nullptr) != PHOVO_OK)
-          return fail("phovo_engine_align_pairs");
+        if (!rccl) {
+          if (phovo_engine_align_pairs(engine, b - a, src.data(), tgt.data(), nullptr, states.data() + (size_t)a * 6, nullptr) != PHOVO_OK)
+            return fail("phovo_engine_align_pairs");
+        } else {
+          void *dStates = nullptr;
+          if (phovo_engine_enqueue_align(engine, b - a, src.data(), tgt.data(), nullptr) != PHOVO_OK) return fail("phovo_engine_enqueue_align");
+          if (phovo_engine_synchronize(engine) != PHOVO_OK) return fail("phovo_engine_synchronize");
+          if (phovo_engine_results_device_ptr(engine, &dStates) != PHOVO_OK) return fail("phovo_engine_results_device_ptr");
+          std::string err;
+          if (!group.all_gather_states(g, dStates, b - a, maxShard, &err)) { shardError[g] = err; phovo_engine_destroy(engine); return; }
+        }
         phovo_engine_destroy(engine);
       };
       {
@@ -275,6 +300,13 @@ int main(int argc, char *argv[])
         for (auto &th : shards) th.join();
       }
       for (const auto &e : shardError) if (!e.empty()) { std::cerr << e << std::endl; return EXIT_FAILURE; }
+      if (rccl) {                          // rank 0's view of the gather: shard g's block holds its (b - a) x 6 states
+        for (int g = 0; g < nGpus; g++) {
+          const int base = nPairs / nGpus, extra = nPairs % nGpus;
+          const int a = g * base + (g < extra ? g : extra), b = a + base + (g < extra ? 1 : 0);
+          std::copy(group.gathered(g), group.gathered(g) + (size_t)(b - a) * 6, states.begin() + (size_t)a * 6);
+        }
+      }
       const auto t1 = std::chrono::steady_clock::now();
       std::cout << "Time = " << std::chrono::duration<double>(t1 - t0).count() << " sec. (" << nPairs << " pairs on " << nGpus
                 << " device(s), upload and pyramids included)" << std::endl;
