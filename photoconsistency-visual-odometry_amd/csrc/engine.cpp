@@ -46,8 +46,6 @@ struct LevelPool {
   bool plan_ok = false;
   GNLaunchPlan plan_few{};             // geometry for a handful of pairs (LATENCY_PAIRS or fewer)
   bool plan_few_ok = false;
-  GNLaunchPlan plan_tail{};            // geometry of the second launch of a capped level (few long pairs, one per CU)
-  bool plan_tail_ok = false;
 };
 
 }  // namespace phovo_hip
@@ -704,7 +702,6 @@ int phovo_engine_reserve_frames(phovo_engine *e, int n_frames, int width, int he
     lv.stored = e->build_all || e->cfg.max_num_iterations[l] > 0;
     lv.plan_ok = gn_plan_level(lv.n, &lv.plan);
     lv.plan_few_ok = gn_plan_level(lv.n, &lv.plan_few, 1);
-    lv.plan_tail_ok = gn_plan_level(lv.n, &lv.plan_tail, 2);
     {   // byte layout of one frame at this level: planes I, D, GX, GY.  fp64: packed [4][n] doubles, which is
         // what the producer kernels write directly; narrow storages: every plane starts 16-byte aligned.
       const bool packed = e->ext.plane_storage == PHOVO_STORAGE_F64;

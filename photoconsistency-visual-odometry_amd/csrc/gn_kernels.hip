@@ -674,9 +674,7 @@ bool gn_plan_level(int n, GNLaunchPlan *plan, int prefer_latency)
   }
   const size_t f512 = lds_fixed_bytes(512), f1024 = lds_fixed_bytes(1024);
   const bool reg512 = n_chunks <= 64 * 8, reg1024 = n_chunks <= 64 * 16;
-  // prefer_latency == 2: the widest workgroup that keeps the owner map in LDS (a pair alone on its CU: 16 waves instead of 8)
-  const bool widest = prefer_latency >= 2 && reg1024 && f1024 + owner_bytes(1024) <= LDS_LIMIT && n_chunks >= 64;
-  if (!tuning_switch("PHOVO_GN_FORCE_WIDE") && !widest && reg512 && f512 + owner_bytes(512) <= LDS_HALF) {
+  if (!tuning_switch("PHOVO_GN_FORCE_WIDE") && reg512 && f512 + owner_bytes(512) <= LDS_HALF) {
     plan->variant = V_MID; plan->threads = 512; plan->wgs_per_cu = 2; plan->owner_in_lds = true; plan->source_in_lds = false;
     plan->lds_bytes = (int)(f512 + owner_bytes(512));
     return true;

@@ -79,8 +79,7 @@ struct GNLaunchPlan {
 
 // Chooses the launch geometry for a level of n pixels.  Returns false if the level cannot be
 // handled (inbound-mask does not fit LDS).
-// prefer_latency 1: the geometry for a handful of pairs (each alone on a CU): 512 threads instead of four workgroups of 256;
-// 2: the widest workgroup whose owner map still fits LDS (1024 threads where the level has at least 64 chunks).
+// prefer_latency 1: the geometry for a handful of pairs (each alone on a CU): 512 threads instead of four workgroups of 256.
 bool gn_plan_level(int n, GNLaunchPlan *plan, int prefer_latency = 0);
 // args.n_pairs pairs, args.work_counter zeroed on the stream beforehand; the grid is min(pairs, CUs x workgroups/CU).
 hipError_t gn_launch_level(const GNLevelArgs &args, const GNLaunchPlan &plan, int storage, int cu_count,

@@ -2,7 +2,7 @@
 
   * scenes that look like what BASELINE.json's configs[2] names -- the layered desk-like scene of synthetic.py (depth
     discontinuities, occlusion, Kinect-style invalid regions and depth noise) -- at 640x480 and 1280x960, on every launch
-    form (persistent, capped launches, wide form, sliding window and its exact fallback), with the collision statistics
+    form (persistent and fused launches, wide form, sliding window and its exact fallback), with the collision statistics
     of the reference's scatter (...Analytic.h:358) printed so that the coverage is visible;
   * phovo_pair_report.valid_pixels against the oracle's count of filled Jacobian rows;
   * phovo_engine_set_batch_invariant: a pair's result does not depend on how the sequence is cut into shards;
@@ -68,7 +68,7 @@ def _print_scatter(tag, p, pyr, ocfg, state):
                                        ("config_5_level_optimization_analytic.yml", False)])
 def test_layered_scenes_640x480_match_oracle_on_every_form(yml, fixed):
     """Six layered pairs (small and large motions: the large ones make sources of DIFFERENT depth layers, 10-20 pixels
-    apart, land on one target) through the shipped configurations: a batch of 60 (persistent kernel, capped launches
+    apart, land on one target) through the shipped configurations: a batch of 60 (persistent kernel, fused launch
     with the shipped thresholds), a batch of 6 (the <= 8-pair latency geometry; level 2 = 160x120 in the wide form) and
     one pair at a time.  Poses, iteration counts, flags and the valid-pixel counts of the report."""
     ncfg0 = native.read_config_file(os.path.join(CFG_DIR, yml))

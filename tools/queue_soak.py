@@ -30,10 +30,10 @@ elif mode == "slide":
 probs = [synthetic.make_pair(21, W, H, holes=0.02, trans=0.004, rot=0.002),
          synthetic.make_pair(22, W, H, holes=0.0, trans=0.03, rot=0.015),
          synthetic.make_pair(23, W, H, holes=0.05, trans=0.06, rot=0.03)]
-if mode == "layered":               # shipped thresholds on the layered scene: two of three problems run long on every level,
-    probs = [synthetic.make_pair(31, W, H, scene="layered", trans=0.05, rot=0.012, invalid=0.25),        # so most pairs are
-             synthetic.make_pair(22, W, H, holes=0.0, trans=0.03, rot=0.015),                            # handed over and the
-             synthetic.make_pair(33, W, H, scene="layered", trans=0.08, rot=0.02, invalid=0.3)]          # side list is long
+if mode == "layered":               # shipped thresholds on the layered scene: two of three problems run long on every level
+    probs = [synthetic.make_pair(31, W, H, scene="layered", trans=0.05, rot=0.012, invalid=0.25),
+             synthetic.make_pair(22, W, H, holes=0.0, trans=0.03, rot=0.015),
+             synthetic.make_pair(33, W, H, scene="layered", trans=0.08, rot=0.02, invalid=0.3)]
 if mode == "slide":                 # one problem that leaves the window: rendered with a large in-plane rotation
     from phovo_amd import se3
     scene = synthetic.Scene(91)
