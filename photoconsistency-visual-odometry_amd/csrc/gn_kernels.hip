@@ -122,7 +122,7 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
 
   const double fx = A.fx, fy = A.fy, ox = A.ox, oy = A.oy, ifx = A.ifx, ify = A.ify;
   const double min_d = A.min_depth, max_d = A.max_depth;
-  const double dW = (double)W, dH = (double)H;
+  const double dW = (double)W;
   // px = (c - ox) * pz * ifx (:282) as fma(c + 0.5, ifx, -(ox + 0.5) * ifx) * pz: one fma and one product
   const double oxi = uniform_f64(-(ox + 0.5) * ifx), oyi = uniform_f64(-oy * ify);
   const double huber_delta = A.huber_delta;
@@ -178,8 +178,8 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
       double pz_next = plane_load<TD>(rS, k, oD);
       // the translation sits in vector registers during this pass (pass 1 has registers to spare): an fma takes one
       // scalar operand, and the rotation entry already is one
-      double cxv = cx * fx, cyv = cyy * fy, czv = cz;
-      asm volatile("" : "+v"(cxv), "+v"(cyv), "+v"(czv));
+      double cxv = cx * fx, cyv = cyy * fy, czv = cz, oxv = oxi, oyv = oyi;
+      asm volatile("" : "+v"(cxv), "+v"(cyv), "+v"(czv), "+v"(oxv), "+v"(oyv));
       // warp of one 64-pixel chunk: ballot of "valid and landed in bounds" and the target index of every lane
       auto warp_chunk = [&](const double pz, const int chunk, unsigned long long &m_out, int &t_out) {
         // No branch around the arithmetic: a lane that fails the depth gate computes on whatever it loaded and is
@@ -187,8 +187,8 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
         // the AND of the compare masks -- scalar work only.
         // depth gate: k < n, min_d < pz < max_d  (:280), folded into the ballot below
         PHOVO_ROWCOL_HERE
-        const double px = fma(cd, ifx, oxi) * pz;                         // :282  ((c - ox) * ifx as one fma)
-        const double py = fma(rd, ify, oyi) * pz;                         // :283
+        const double px = fma(cd, ifx, oxv) * pz;                         // :282  ((c - ox) * ifx as one fma)
+        const double py = fma(rd, ify, oyv) * pz;                         // :283
         const double Xf = fma(fr02, pz, fma(fr01, py, fma(fr00, px, cxv)));      // fx * (Rt*point3D).x  :291,295
         const double Yf = fma(fr12, pz, fma(fr11, py, fma(fr10, px, cyv)));
         const double Z = fma(t2, pz, fma(t1, py, fma(-t3, px, czv)));
@@ -197,7 +197,12 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
         const double tr = fma(Yf, iz, oy);                                // :296
         // C round(), half away from zero (:297-298), then 0 <= . < size (:302-303): round(v) >= 0 iff v > -0.5
         // (NaN fails every comparison)
-        const double rr = round_half_up_from(tr), rc = round_half_up_from(tc);
+        // round() of a coordinate that passes `> -0.5` is floor(v + p) with p the largest double below one half
+        // (round_half_up_from, gn_device.hpp) and v + p >= 0 there, so the conversion to int -- which truncates -- IS that
+        // floor: one add + one conversion per coordinate, the upper bounds as 32-bit compares, the target index as one
+        // integer multiply-add.  A coordinate beyond the int range saturates and fails the upper bound; NaN fails `> -0.5`.
+        const double half_below = __hiloint2double(0x3fdfffff, (int)0xffffffff);
+        const int ri = __double2int_rz(tr + half_below), ci = __double2int_rz(tc + half_below);
         // One ballot per comparison, ANDed on the scalar unit: the ballot of an AND of comparisons would be
         // rebuilt lane by lane (v_cndmask + v_cmp) by this compiler.
         // (k < n is a property of the chunk, not of the lane: the lanes of the image's last, partial chunk -- scalar unit)
@@ -206,10 +211,10 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
         const unsigned long long m =
             in_image & __builtin_amdgcn_ballot_w64(min_d < pz) &
             __builtin_amdgcn_ballot_w64(pz < max_d) & __builtin_amdgcn_ballot_w64(tr > -0.5) &
-            __builtin_amdgcn_ballot_w64(rr < dH) & __builtin_amdgcn_ballot_w64(tc > -0.5) &
-            __builtin_amdgcn_ballot_w64(rc < dW);
+            __builtin_amdgcn_ballot_w64(ri < H) & __builtin_amdgcn_ballot_w64(tc > -0.5) &
+            __builtin_amdgcn_ballot_w64(ci < W);
         m_out = m;
-        t_out = (int)fma(rr, dW, rc);                                     // exact in fp64: one fma + one conversion
+        t_out = ri * W + ci;
       };
       auto keep_mask = [&](const unsigned long long m, const int chunk) {
         if (!MASK_REG) n_rows += __builtin_popcountll(m);
