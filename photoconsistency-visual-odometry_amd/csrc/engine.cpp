@@ -1085,6 +1085,7 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
     return gn_level_fusable(lv.n);
   };
 
+  int split_until = -1;        // PHOVO_FUSION_SPLIT: the levels down to this one belong to the run whose first launch has gone out
   for (int l = e->cfg.num_levels - 1; l >= 0; l--) {                                 // coarse to fine  :502-503
     if (e->cfg.max_num_iterations[l] <= 0) continue;                                 // :526 (nothing observable happens)
     const LevelPool &lv = e->levels[l];
@@ -1106,6 +1107,8 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
         run[n_run++] = m;
         if (e->cfg.min_gradient_norm[m] > 0.0) data_dependent = true;
       }
+      if (l >= split_until && split_until >= 0) { n_run = 2; data_dependent = true; }        // a later level of a split run
+      else if (n_run >= 2 && data_dependent && e->fusion == PHOVO_FUSION_SPLIT) split_until = run[n_run - 1];
       if (n_run >= 2 && data_dependent && e->fusion == PHOVO_FUSION_AUTO) {
         GNFusedArgs f{};
         f.n_levels = n_run; f.n_pairs = n_pairs; f.n_queues = a.n_queues; f.work_counter = a.work_counter;
