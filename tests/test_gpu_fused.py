@@ -201,3 +201,35 @@ def test_two_enqueues_in_flight_change_nothing_but_the_clock():
         assert np.array_equal(got[k][0], serial[k][0]), k
         assert all(list(a.iterations[:4]) == list(b.iterations[:4]) and a.gradient_norm == b.gradient_norm and a.flags == b.flags
                    for a, b in zip(got[k][1], serial[k][1])), k
+
+
+def test_fused_run_of_two_small_levels_at_another_image_size():
+    """448x336: levels 3 and 2 are 56x42 and 112x84 pixels -- both would take the 256-thread geometry on their own, fused they
+    take the 512-thread one.  Fused, the same geometry level by level (PHOVO_FUSION_SPLIT: bit-identical, also on the LAST
+    level of the run, whose own plan would differ) and one launch per level in each level's own geometry all match the
+    oracle."""
+    p = synthetic.make_pair(77, 448, 336, holes=0.02, trans=0.02, rot=0.01)
+    nl, max_iter, min_grad = 4, [0, 0, 7, 11], [0.0, 0.0, 120.0, 120.0]
+    ncfg = native.make_config(num_levels=nl, max_iter=max_iter, min_grad=min_grad)
+    ocfg = oracle.make_config(num_levels=nl, max_iter=max_iter, min_grad=min_grad)
+    es, eits = oracle.align_frames(ocfg, p["K"], p["gray0"], p["depth0"], p["gray1"])
+    out, launches = {}, {}
+    with odometry.AlignmentEngine() as eng:
+        eng.set_config(ncfg)
+        eng.set_intrinsic_matrix(p["K"])
+        eng.reserve_frames(2, 448, 336)
+        eng.upload_frame(0, p["gray0"], p["depth0"], roles=native.ROLE_SOURCE)
+        eng.upload_frame(1, p["gray1"], None, roles=native.ROLE_TARGET)
+        assert eng.level_size(3) == (56, 42) and eng.level_size(2) == (112, 84)
+        for mode in (native.FUSION_AUTO, native.FUSION_SPLIT, native.FUSION_OFF):
+            eng.set_level_fusion(mode)
+            out[mode] = eng.align_pairs([0] * 300, [1] * 300, want_reports=True)
+            launches[mode] = [(r["kind"], r["threads"]) for r in eng.last_launches()]
+    assert launches[native.FUSION_AUTO] == [("fused", 512)]
+    assert launches[native.FUSION_SPLIT] == [("persistent", 512), ("persistent", 512)]
+    assert launches[native.FUSION_OFF] == [("persistent", 256), ("persistent", 256)]
+    for mode, (s, r) in out.items():
+        assert list(r[0].iterations[:nl]) == eits, (mode, list(r[0].iterations[:nl]), eits)
+        assert se3.state_distance(s[0], es) < POSE_TOL, (mode, se3.state_distance(s[0], es))
+        assert all(np.array_equal(s[0], s[k]) for k in range(300))
+    assert np.array_equal(out[native.FUSION_AUTO][0], out[native.FUSION_SPLIT][0])
