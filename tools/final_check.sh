@@ -1,4 +1,5 @@
 #!/bin/bash
+# What the driver runs at round end, on the GPU box (through gpurun): pytest -m gpu, the default bench.py line, smoke().
 set -o pipefail
 O=gpurun_out/r4z
 mkdir -p $O
