@@ -308,8 +308,17 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
     // reference path (no Huber weights) carries none of the extension's instructions.
     auto pass2 = [&](auto huber_tag) {
       constexpr bool HUBER = decltype(huber_tag)::value;
-      int k = k0, j = 0;
-      PHOVO_ROWCOL_BEGIN
+      // With the owner map in LDS a wave walks its chunks BACKWARDS here: pass 1 has just read the depth plane front to
+      // back and the next iteration's pass 1 will start at the front again, so the depth lines this pass meets first and
+      // last are the ones an XCD's L2 (4 MB shared by 64 workgroups: a line lives a few microseconds) still holds from
+      // the pass before / keeps for the pass after.  The kernel is bound by bytes at the fabric; the
+      // second read of the depth plane is the only plane traffic that is not algorithmic.
+      constexpr bool REV = OWNER_LDS;
+      const int my_chunks = wave < A.n_chunks ? (A.n_chunks - 1 - wave) / NW + 1 : 0;       // wave-uniform
+      const int first = REV ? my_chunks - 1 : 0;                                            // position of the first chunk taken
+      const int k_step = REV ? -NW * WAVE : NW * WAVE;
+      int k = k0 + first * (NW * WAVE), j = first;
+      double kd = kd0 + (double)first * kd_step, cd, rd;
       // software prefetch, as in pass 1: owner + four planes of the NEXT chunk are requested (and the
       // gathered source intensity right behind them) before this chunk's arithmetic starts.
       int o_n = -1;
@@ -326,8 +335,10 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
       auto fetch = [&](int kk) {
         o_n = -1;
         if (OWNER_LDS) {
-          o_n = s_owner[kk];                        // (past the image: the padding, -1)
-          s_owner[kk] = -1;                         // ready for the next iteration
+          if (kk >= 0) {                            // (wave-uniform: walking backwards, the chunk in front of the first)
+            o_n = s_owner[kk];                      // (past the image: the padding, -1)
+            s_owner[kk] = -1;                       // ready for the next iteration
+          }
         } else {
           if (kk < n_lds) {                         // n_lds is a multiple of 64: the whole chunk is on one side
             o_n = s_owner[kk];
@@ -348,7 +359,7 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
       auto chunk_body = [&](const int chunk) {
         const int o = o_n;
         const double pz = pz_n, gxi = gx_n, gyi = gy_n, pixel2 = i1_n, pixel1 = i0_n;
-        fetch(k + NW * WAVE);
+        fetch(k + k_step);
         const unsigned long long mbits =
             MASK_REG ? (((unsigned long long)(unsigned)__builtin_amdgcn_readlane(inb_hi, j) << 32) |
                         (unsigned long long)(unsigned)__builtin_amdgcn_readlane(inb_lo, j))
@@ -407,14 +418,21 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
 #pragma unroll
           for (int a = 0; a < 6; a++) acc[21 + a] = fma(Jw[a], res, acc[21 + a]);        // J^T (W) r  :538
         }
-        k += NW * WAVE;
-        j++;
-        PHOVO_ROWCOL_NEXT
+        k += k_step;
+        j += REV ? -1 : 1;
+        kd += REV ? -kd_step : kd_step;
       };
       // two chunks per trip by hand, as in pass 1
-      for (int chunk = wave; chunk < A.n_chunks; chunk += 2 * NW) {
-        chunk_body(chunk);
-        if (chunk + NW < A.n_chunks) chunk_body(chunk + NW);
+      if (REV) {
+        for (int c = my_chunks - 1; c >= 0; c -= 2) {
+          chunk_body(wave + c * NW);
+          if (c >= 1) chunk_body(wave + (c - 1) * NW);
+        }
+      } else {
+        for (int chunk = wave; chunk < A.n_chunks; chunk += 2 * NW) {
+          chunk_body(chunk);
+          if (chunk + NW < A.n_chunks) chunk_body(chunk + NW);
+        }
       }
     };
     if (huber_on) pass2(std::true_type{}); else pass2(std::false_type{});
