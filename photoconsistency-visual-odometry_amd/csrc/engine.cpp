@@ -1150,6 +1150,7 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
       const GNLaunchPlan &pl = few ? lv.plan_few : lv.plan;
       a.n_lds = pl.owner_in_lds ? 0 : pl.owner_lds_entries;
       a.g_mask = pl.mask_in_hbm ? s.d_mask : nullptr;
+      a.depth_lds_chunks = pl.depth_lds_chunks;
       int *list0 = s.d_handover + (size_t)l * lay.handover_stride;
       int *heads1 = s.d_work_counters + (PHOVO_MAX_LEVELS + l) * QUEUE_HEADS_INTS;
       if (!pl.owner_in_lds && e->slide_policy >= 0) {

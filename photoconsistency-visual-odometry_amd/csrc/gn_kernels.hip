@@ -63,8 +63,9 @@ struct LevelLds {
 // T threads per workgroup.  SRC_LDS: source intensity plane staged in LDS.  OWNER_LDS: owner map in LDS (else in global
 // memory).  MASK_REG: the per-pixel "warped in bounds" flags of a lane live in one 64-bit register (needs <= 64 chunks
 // per wave), else in an LDS ballot array.  TI / TD: storage type of the intensity+gradient planes / of the depth plane
-// (double = reference-exact).
-template <int T, bool SRC_LDS, bool OWNER_LDS, bool MASK_REG, typename TI, typename TD>
+// (double = reference-exact).  PARK (owner map in LDS, no SRC_LDS): whatever LDS the geometry leaves unused keeps the depth of
+// the image's leading A.depth_lds_chunks chunks from pass 1 to pass 2 (the block L.i0).
+template <int T, bool SRC_LDS, bool OWNER_LDS, bool MASK_REG, typename TI, typename TD, bool PARK = false>
 __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds &L, const int pair, const bool state_in_lds,
                                            int &iteration, double &last_gnorm, int &last_valid)
 {
@@ -80,6 +81,7 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
   const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
   const int n = A.n, W = A.w, H = A.h;
   const int n_lds = OWNER_LDS ? 0 : A.n_lds;      // owner map in HBM: targets below n_lds are resolved in LDS all the same
+  const int depth_chunks = PARK ? A.depth_lds_chunks : 0;
 
   const unsigned char *src_frame = A.planes + (size_t)A.src[pair] * A.frame_bytes;
   const unsigned char *tgt_frame = A.planes + (size_t)A.tgt[pair] * A.frame_bytes;
@@ -229,6 +231,10 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
         auto chunk_body = [&](const int chunk) {
           const double pz = pz_next;                                      // :279
           pz_next = plane_load<TD>(rS, k + NW * WAVE, oD);                   // (past the plane: masked out)
+          // The depth plane is the one plane both passes read.  Whatever LDS this geometry leaves unused keeps the depth of
+          // the image's LEADING chunks for pass 2 (the same lane reads back what it wrote); pass 2 walks backwards, so the
+          // trailing chunks -- read last here -- still come from the XCD's L2.  The kernel is bound by bytes at the fabric.
+          if (PARK && chunk < depth_chunks) s_i0[k] = pz;                 // (wave-uniform; s_i0: the block behind the owner map)
           unsigned long long m;
           int t;
           warp_chunk(pz, chunk, m, t);
@@ -332,7 +338,7 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
         o_raw = (kk >= n_lds && kk < n) ? __hip_atomic_load(&g_owner[kk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
       };
       if (!OWNER_LDS) owner_request(k);
-      auto fetch = [&](int kk) {
+      auto fetch = [&](int kk, auto parked_tag) {      // parked_tag: the chunk's depth was parked in LDS by pass 1
         o_n = -1;
         if (OWNER_LDS) {
           if (kk >= 0) {                            // (wave-uniform: walking backwards, the chunk in front of the first)
@@ -348,18 +354,19 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
           }
           owner_request(kk + NW * WAVE);
         }
-        pz_n = plane_load<TD>(rS, kk, oD);
+        if constexpr (decltype(parked_tag)::value) pz_n = s_i0[max(kk, 0)];      // (kk < 0: the chunk in front of the first, unused)
+        else pz_n = plane_load<TD>(rS, kk, oD);
         gx_n = plane_load<TI>(rT, kk, oGX);             // gradient at the SOURCE index  :346-347
         gy_n = plane_load<TI>(rT, kk, oGY);
         i1_n = plane_load<TI>(rT, kk, oI);             // :309
         if (SRC_LDS) { if (o_n >= 0) i0_n = s_i0[o_n]; }
         else i0_n = plane_load<TI>(rS, o_n, oI);       // :308 of the owning source pixel (o = -1: offset past the plane -> 0)
       };
-      fetch(k);
-      auto chunk_body = [&](const int chunk) {
+      if (PARK && wave + first * NW < depth_chunks) fetch(k, std::true_type{}); else fetch(k, std::false_type{});
+      auto chunk_body = [&](const int chunk, auto next_parked_tag) {
         const int o = o_n;
         const double pz = pz_n, gxi = gx_n, gyi = gy_n, pixel2 = i1_n, pixel1 = i0_n;
-        fetch(k + k_step);
+        fetch(k + k_step, next_parked_tag);
         const unsigned long long mbits =
             MASK_REG ? (((unsigned long long)(unsigned)__builtin_amdgcn_readlane(inb_hi, j) << 32) |
                         (unsigned long long)(unsigned)__builtin_amdgcn_readlane(inb_lo, j))
@@ -424,14 +431,27 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
       };
       // two chunks per trip by hand, as in pass 1
       if (REV) {
-        for (int c = my_chunks - 1; c >= 0; c -= 2) {
-          chunk_body(wave + c * NW);
-          if (c >= 1) chunk_body(wave + (c - 1) * NW);
+        // positions c_hi .. c_lo of this wave's chunks, downwards; `tag`: is the chunk BEHIND each of them parked?
+        auto run = [&](int c_hi, int c_lo, auto tag) {
+          for (int c = c_hi; c >= c_lo; c -= 2) {
+            chunk_body(wave + c * NW, tag);
+            if (c > c_lo) chunk_body(wave + (c - 1) * NW, tag);
+          }
+        };
+        if (PARK) {
+          // position c's successor is chunk wave + (c - 1) * NW: parked iff that is below depth_chunks (position 0's lies
+          // in front of the image: read from the parked block too, clamped, unused)
+          // (no chunk of this wave parked: -1, everything in the first run)
+          const int c_split = depth_chunks > wave ? min(my_chunks - 1, (depth_chunks - 1 - wave) / NW + 1) : -1;
+          run(my_chunks - 1, c_split + 1, std::false_type{});
+          run(min(my_chunks - 1, c_split), 0, std::true_type{});
+        } else {
+          run(my_chunks - 1, 0, std::false_type{});
         }
       } else {
         for (int chunk = wave; chunk < A.n_chunks; chunk += 2 * NW) {
-          chunk_body(chunk);
-          if (chunk + NW < A.n_chunks) chunk_body(chunk + NW);
+          chunk_body(chunk, std::false_type{});
+          if (chunk + NW < A.n_chunks) chunk_body(chunk + NW, std::false_type{});
         }
       }
     };
@@ -549,7 +569,7 @@ __device__ __forceinline__ LevelLds carve_lds(unsigned char *lds_raw, int n_max,
 // The owner map in LDS is wiped ONCE per workgroup: pass 2 resets every slot it reads, and it reads all of them.
 // It is padded to whole chunks plus one round of the workgroup (owner_lds_entries): pass 2 fetches the owner a chunk
 // ahead without asking whether that chunk still exists -- the padding reads -1, "nobody", and pass 1 never writes there.
-template <int T, int WPS, bool SRC_LDS, bool OWNER_LDS, bool MASK_REG, typename TI, typename TD>
+template <int T, int WPS, bool SRC_LDS, bool OWNER_LDS, bool MASK_REG, typename TI, typename TD, bool PARK = false>
 __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
 {
   extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -572,7 +592,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
     if (A.handover_in) iteration = __builtin_amdgcn_readfirstlane(A.reports[pair].iterations[A.level]);
     double last_gnorm = 0.0;
     int last_valid = 0;
-    level_body<T, SRC_LDS, OWNER_LDS, MASK_REG, TI, TD>(A, L, pair, false, iteration, last_gnorm, last_valid);
+    level_body<T, SRC_LDS, OWNER_LDS, MASK_REG, TI, TD, PARK>(A, L, pair, false, iteration, last_gnorm, last_valid);
 
     // ---- epilogue: state and report back to HBM -------------------------------------------------
     if (tid == 0) {
@@ -656,11 +676,11 @@ enum Variant { V_TINY = 0, V_MID, V_WIDE, V_HUGE, V_QUAD, V_SOLO };
 // ... times the three plane storages (fp64 = reference-exact; fp32; fp16 images + fp32 depth).
 //   SOLO   64 threads, 16 workgroups/CU: one wave per pair (levels of <= 2048 pixels in a throughput launch)
 #define PHOVO_KERNEL_TINY(TI, TD)  gn_level_kernel<256, 4, true, true, true, TI, TD>
-#define PHOVO_KERNEL_MID(TI, TD)   gn_level_kernel<512, 4, false, true, true, TI, TD>
-#define PHOVO_KERNEL_WIDE(TI, TD)  gn_level_kernel<1024, 4, false, true, true, TI, TD>
+#define PHOVO_KERNEL_MID(TI, TD)   gn_level_kernel<512, 4, false, true, true, TI, TD, true>
+#define PHOVO_KERNEL_WIDE(TI, TD)  gn_level_kernel<1024, 4, false, true, true, TI, TD, true>
 #define PHOVO_KERNEL_HUGE(TI, TD)  gn_level_kernel<1024, 4, false, false, false, TI, TD>
-#define PHOVO_KERNEL_QUAD(TI, TD)  gn_level_kernel<256, 4, false, true, true, TI, TD>
-#define PHOVO_KERNEL_SOLO(TI, TD)  gn_level_kernel<64, 4, false, true, true, TI, TD>
+#define PHOVO_KERNEL_QUAD(TI, TD)  gn_level_kernel<256, 4, false, true, true, TI, TD, true>
+#define PHOVO_KERNEL_SOLO(TI, TD)  gn_level_kernel<64, 4, false, true, true, TI, TD, true>
 #define PHOVO_KERNEL_FUSED(TI, TD) gn_fused_kernel<512, 4, TI, TD>
 
 }  // namespace
@@ -669,8 +689,17 @@ bool gn_plan_level(int n, GNLaunchPlan *plan, int prefer_latency)
 {
   plan->owner_lds_entries = 0;
   plan->mask_in_hbm = false;
+  plan->depth_lds_chunks = 0;
   const size_t n_chunks = (size_t)(n + WAVE - 1) / WAVE;
   auto owner_bytes = [n](int threads) { return sizeof(int) * (size_t)owner_lds_entries(n, threads); };
+  // leftover LDS of a geometry with `per_cu` workgroups per CU -> leading chunks whose depth pass 1 parks there (PARK)
+  auto park_depth = [&](size_t used, int per_cu) {
+    used = (used + 7) & ~(size_t)7;
+    const size_t room = LDS_LIMIT / (size_t)per_cu;
+    const size_t chunks = room > used ? (room - used) / (sizeof(double) * WAVE) : 0;
+    plan->depth_lds_chunks = (int)(chunks < n_chunks ? chunks : n_chunks);
+    return used + sizeof(double) * WAVE * (size_t)plan->depth_lds_chunks;
+  };
   const size_t src = sizeof(double) * (size_t)n;
   // Levels of <= 2048 pixels in a throughput launch: ONE WAVE per pair, 16 workgroups per CU.  An iteration of such a level
   // is short (40x30: 19 chunks) and a third of a 256-thread workgroup's time per iteration is wave 0's serial section
@@ -678,7 +707,7 @@ bool gn_plan_level(int n, GNLaunchPlan *plan, int prefer_latency)
   // waits -- the other 15 pairs of the CU fill the SIMDs meanwhile.
   if (n <= 2048 && !prefer_latency && !tuning_switch("PHOVO_GN_NO_SOLO") && n_chunks <= 64) {
     plan->variant = V_SOLO; plan->threads = 64; plan->wgs_per_cu = 16; plan->owner_in_lds = true; plan->source_in_lds = false;
-    plan->lds_bytes = (int)(lds_fixed_bytes(64) + owner_bytes(64));
+    plan->lds_bytes = (int)park_depth(lds_fixed_bytes(64) + owner_bytes(64), 16);
     return true;
   }
   if (n <= 2048) {
@@ -692,19 +721,24 @@ bool gn_plan_level(int n, GNLaunchPlan *plan, int prefer_latency)
   // (one pair alone on a CU: 12.4 us per 80x60 iteration with 256 threads, 10.1 us with 512 -- prefer_latency)
   if (!tuning_switch("PHOVO_GN_NO_QUAD") && !prefer_latency && n_chunks <= 64 * 4 && f256 + owner_bytes(256) <= LDS_LIMIT / 4) {
     plan->variant = V_QUAD; plan->threads = 256; plan->wgs_per_cu = 4; plan->owner_in_lds = true; plan->source_in_lds = false;
-    plan->lds_bytes = (int)(f256 + owner_bytes(256));
+    plan->lds_bytes = (int)park_depth(f256 + owner_bytes(256), 4);
     return true;
   }
   const size_t f512 = lds_fixed_bytes(512), f1024 = lds_fixed_bytes(1024);
   const bool reg512 = n_chunks <= 64 * 8, reg1024 = n_chunks <= 64 * 16;
+  const bool fits_wide = reg1024 && f1024 + owner_bytes(1024) <= LDS_LIMIT;
   if (!tuning_switch("PHOVO_GN_FORCE_WIDE") && reg512 && f512 + owner_bytes(512) <= LDS_HALF) {
     plan->variant = V_MID; plan->threads = 512; plan->wgs_per_cu = 2; plan->owner_in_lds = true; plan->source_in_lds = false;
-    plan->lds_bytes = (int)(f512 + owner_bytes(512));
-    return true;
+    plan->lds_bytes = (int)park_depth(f512 + owner_bytes(512), 2);
+    // A level whose owner map fills a half of LDS (160x120: 77 of 80 KB) leaves two workgroups per CU no room to park
+    // depth, while ONE workgroup of 1024 threads parks half the image next to the same map: 19.25 -> 18.98 ms per 512 pairs
+    // x 50 iterations of 160x120 (profiles/r04_runs/park_depth_ab.txt).  Throughput launches only.
+    const bool mid_parks_little = (size_t)plan->depth_lds_chunks * 4 < n_chunks;
+    if (!(mid_parks_little && fits_wide && !prefer_latency && !tuning_switch("PHOVO_GN_NO_WIDE_PARK"))) return true;
   }
-  if (reg1024 && f1024 + owner_bytes(1024) <= LDS_LIMIT) {
+  if (fits_wide) {
     plan->variant = V_WIDE; plan->threads = 1024; plan->wgs_per_cu = 1; plan->owner_in_lds = true; plan->source_in_lds = false;
-    plan->lds_bytes = (int)(f1024 + owner_bytes(1024));
+    plan->lds_bytes = (int)park_depth(f1024 + owner_bytes(1024), 1);
     return true;
   }
   size_t mask = sizeof(unsigned long long) * n_chunks;
@@ -733,7 +767,7 @@ bool gn_plan_fused_geometry(int n, GNLaunchPlan *plan)
 {
   if (!gn_level_fusable(n)) return false;
   plan->variant = V_MID; plan->threads = 512; plan->wgs_per_cu = 2; plan->owner_in_lds = true; plan->source_in_lds = false;
-  plan->owner_lds_entries = 0;
+  plan->owner_lds_entries = 0; plan->mask_in_hbm = false; plan->depth_lds_chunks = 0;
   plan->lds_bytes = gn_fused_lds_bytes(n);
   return true;
 }

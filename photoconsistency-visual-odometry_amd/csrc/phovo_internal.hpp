@@ -39,6 +39,8 @@ struct GNLevelArgs {
   int *work_counter;        // [QUEUES_PER_LEVEL] heads QUEUE_HEAD_STRIDE ints apart, zeroed before the launch: workgroups draw pair indices from them
   int n_queues;             // 1: one queue for the whole grid; 8: one per XCD over a contiguous eighth of the pairs (+ stealing)
   int n_lds;                // owner map in HBM only: its first n_lds entries (a multiple of 64) live in LDS instead
+  int depth_lds_chunks;     // owner map in LDS: the depth of the first this-many 64-pixel chunks is kept in leftover LDS by pass 1
+                            // and read from there by pass 2 (0: none)
   // Hand-over of pairs from the sliding-window launch of a level to the exact launch right behind it (same stream).  A
   // list is [n_pairs + 1] ints, zeroed before the first launch: pair indices, and at [n_pairs] their number.
   //   handover_out  non-null (sliding-window kernel): a pair whose warp leaves the window is appended there (its state and
@@ -75,6 +77,7 @@ struct GNLaunchPlan {
   bool source_in_lds;
   int owner_lds_entries;    // owner map in HBM: how many of its leading entries the leftover LDS holds (GNLevelArgs::n_lds)
   bool mask_in_hbm;         // owner map in HBM and a level so large that the per-chunk ballots do not fit LDS either
+  int depth_lds_chunks;     // leading 64-pixel chunks whose depth pass 1 parks in the LDS this geometry leaves unused (GNLevelArgs)
 };
 
 // Chooses the launch geometry for a level of n pixels.  Returns false if the level cannot be

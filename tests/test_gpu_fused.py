@@ -159,7 +159,7 @@ def test_small_batches_and_thresholds_of_zero_take_one_launch_per_level():
         eng.set_config(fixed)
         eng.align_pairs([0] * 64, [1] * 64)
         ls = eng.last_launches()
-        assert [r["kind"] for r in ls] == ["persistent", "persistent"] and [r["threads"] for r in ls] == [256, 512], ls
+        assert [r["kind"] for r in ls] == ["persistent", "persistent"] and [r["threads"] for r in ls] == [256, 1024], ls
 
 
 def test_two_enqueues_in_flight_change_nothing_but_the_clock():

@@ -634,8 +634,10 @@ def test_upload_from_page_locked_caller_memory_and_many_chunks():
     ((40, 30), dict(threads=64, owner_in_lds=True, source_in_lds=False)),       # SOLO: one wave per pair, 16 per CU (TINY, 256
                                                                                 # threads with everything in LDS, for <= 8 pairs)
     ((80, 60), dict(threads=256, owner_in_lds=True, source_in_lds=False)),      # QUAD: 4 workgroups per CU
-    ((160, 120), dict(threads=512, owner_in_lds=True, source_in_lds=False)),    # MID: 2 workgroups per CU
-    ((200, 152), dict(threads=1024, owner_in_lds=True, source_in_lds=False)),   # WIDE: one 1024-thread workgroup
+    ((128, 96), dict(threads=512, owner_in_lds=True, source_in_lds=False)),     # MID: 2 workgroups per CU
+    ((160, 120), dict(threads=1024, owner_in_lds=True, source_in_lds=False)),   # WIDE: one 1024-thread workgroup, because two of
+                                                                                # 512 would have no LDS left to park depth in
+    ((200, 152), dict(threads=1024, owner_in_lds=True, source_in_lds=False)),   # WIDE: the owner map alone needs it
     ((320, 240), dict(threads=512, owner_in_lds=False, source_in_lds=False)),   # SLIDE: owner ring in LDS (+ HUGE: map in HBM)
 ])
 def test_every_kernel_variant_matches_oracle(size, expect):
@@ -651,6 +653,9 @@ def test_every_kernel_variant_matches_oracle(size, expect):
         info = eng.level_launch_info(0)
         for k, v in expect.items():
             assert info[k] == v, (k, info)
+        if info["owner_in_lds"]:      # these geometries park the depth of the leading chunks in whatever LDS is left: all of the
+            per_cu = {64: 16, 256: 4, 512: 2, 1024: 1}[info["threads"]]       # workgroup's share is taken (to within a chunk)
+            assert 160 * 1024 // per_cu - 512 - 8 < info["lds_bytes"] <= 160 * 1024 // per_cu, info
         eng.upload_frame(0, p["gray0"], p["depth0"], roles=native.ROLE_SOURCE)
         eng.upload_frame(1, p["gray1"], None, roles=native.ROLE_TARGET)
         s, reps = eng.align_pairs([0] * 9, [1] * 9, want_reports=True)      # 9 pairs: the throughput geometry above
