@@ -1158,8 +1158,9 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
         // window are put on the hand-over list and continued, from the iteration they had reached, by the exact kernel
         // right behind it, which draws from that list.
         a.handover_out = list0;
+        a.slide_m = gn_slide_reach_bands(lv.w, lv.h);
         PHOVO_HIP_CHECK(gn_launch_level_slide(a, e->ext.plane_storage, e->cu_count, s.stream));
-        record(l, l, PHOVO_LAUNCH_SLIDE, 512, (int)gn_slide_lds_bytes(), persistent_grid(1));
+        record(l, l, PHOVO_LAUNCH_SLIDE, gn_slide_threads(), (int)gn_slide_lds_bytes(), persistent_grid(1));
         a.handover_out = nullptr; a.handover_in = list0; a.takeover_flag = PHOVO_PAIR_WINDOW_FALLBACK;
         a.work_counter = heads1; a.n_queues = 1;
         PHOVO_HIP_CHECK(gn_launch_level(a, pl, e->ext.plane_storage, e->cu_count, s.stream));
@@ -1316,7 +1317,7 @@ int phovo_engine_level_launch_info(const phovo_engine *e, int level, int *thread
   const LevelPool &lv = e->levels[level];
   if (!lv.plan_ok) return fail(PHOVO_E_SHAPE, "level too large for the device path");
   if (!lv.plan.owner_in_lds && e->slide_policy >= 0) {       // the sliding-window kernel runs first on such a level
-    if (threads) *threads = 512;
+    if (threads) *threads = gn_slide_threads();
     if (lds_bytes) *lds_bytes = (int)gn_slide_lds_bytes();
     if (owner_in_lds) *owner_in_lds = 0;                     // a ring of 32768 entries, not the whole map
     if (source_in_lds) *source_in_lds = 0;

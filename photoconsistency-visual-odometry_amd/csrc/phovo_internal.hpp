@@ -39,6 +39,7 @@ struct GNLevelArgs {
   int *work_counter;        // [QUEUES_PER_LEVEL] heads QUEUE_HEAD_STRIDE ints apart, zeroed before the launch: workgroups draw pair indices from them
   int n_queues;             // 1: one queue for the whole grid; 8: one per XCD over a contiguous eighth of the pairs (+ stealing)
   int n_lds;                // owner map in HBM only: its first n_lds entries (a multiple of 64) live in LDS instead
+  int slide_m;              // sliding-window kernel: bands a target may lie away from its source's band (gn_slide_reach_bands)
   int depth_lds_chunks;     // owner map in LDS: the depth of the first this-many 64-pixel chunks is kept in leftover LDS by pass 1
                             // and read from there by pass 2 (0: none)
   // Hand-over of pairs from the sliding-window launch of a level to the exact launch right behind it (same stream).  A
@@ -108,7 +109,8 @@ hipError_t gn_prepare_kernels();   // raises the dynamic-LDS limit of every inst
 hipError_t gn_prepare_slide_kernels();
 hipError_t gn_launch_level_slide(const GNLevelArgs &args, int storage, int cu_count, hipStream_t stream);
 size_t gn_slide_lds_bytes();
-int gn_slide_window_pixels();      // a target may lie this many pixels (linear index) before / after its source's band
+int gn_slide_threads();
+int gn_slide_reach_bands(int w, int h);      // GNLevelArgs::slide_m for a level of w x h pixels
 
 // Pyramid producers (SetSourceFrame / SetTargetFrame, ...Analytic.h:466-491), batched over `frames`
 // consecutive frames: frame f reads src + f*src_frame_stride and writes dst + f*dst_frame_stride (elements).

@@ -638,7 +638,8 @@ def test_upload_from_page_locked_caller_memory_and_many_chunks():
     ((160, 120), dict(threads=1024, owner_in_lds=True, source_in_lds=False)),   # WIDE: one 1024-thread workgroup, because two of
                                                                                 # 512 would have no LDS left to park depth in
     ((200, 152), dict(threads=1024, owner_in_lds=True, source_in_lds=False)),   # WIDE: the owner map alone needs it
-    ((320, 240), dict(threads=512, owner_in_lds=False, source_in_lds=False)),   # SLIDE: owner ring in LDS (+ HUGE: map in HBM)
+    ((320, 240), dict(threads=768, owner_in_lds=False, source_in_lds=False)),   # SLIDE: owner ring in LDS, 4 waves of pass 1
+                                                                                # beside 8 of pass 2 (+ HUGE: map in HBM)
 ])
 def test_every_kernel_variant_matches_oracle(size, expect):
     """One single-level problem per launch geometry of gn_plan_level, each checked against the oracle."""
