@@ -7,6 +7,12 @@
 // chunk): the taps are not what bounds it -- two workgroups per CU hide each other's gathers and serial sections, one
 // workgroup of 12 waves has nobody to hide its solve behind -- and the sliding ring (a barrier and a row prefetch per 768
 // pixels) was 2.5x slower.
+// Also measured and not kept (round 4, profiles/r04_runs/bilinear_roles_ab.txt): two kinds of waves as in the sliding-window
+// kernel -- samplers (warp, taps, interpolation) leave depth, 1/Z', residual and both gradients in LDS, accumulators build
+// the Jacobian row and the 27 sums a band later.  Parity-green; 512 threads x 2 per CU with one chunk of taps in flight per
+// sampler: 162 k alignments/s against this kernel's 178 k on fp64 planes, 188 k against 186 k on fp16 planes (two chunks in
+// flight need 168 registers for fp64 taps: 126-150 k at three waves per SIMD).  What the sliding-window kernel gained from
+// the split -- a wave of arithmetic beside two of memory traffic -- this kernel already has: its two pipeline stages are that.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 

@@ -422,68 +422,83 @@ __device__ __forceinline__ void rowcol_from_index_floor(double kd, const RowColF
   cd = fma(-rd, m.w, kd);
 }
 
-// Wave butterfly + cross-wave sum + solve + update + termination, as in gn_level_kernel's tail, for kernels
-// that keep their 27 sums in `acc`.  Returns after the closing barrier; the caller reads s_ctl[CTL_DONE].
-template <int NW>
-__device__ __forceinline__ void reduce_solve_update(double (&acc)[NRED], int lane, int wave, double *s_red,
-                                                    double *s_state, double *s_cst, int *s_ctl,
-                                                    double lambda, int max_iter, double min_grad_norm,
-                                                    int iteration, double &last_gnorm, int &last_valid)
+// A wave's 27 sums (+ the row count) folded over its 64 lanes and written to row `row` of s_red (transposed butterfly).
+__device__ __forceinline__ void reduce_wave_to_row(double (&acc)[NRED], int lane, int row, double *s_red)
 {
   reduce_stage_swap<32, false>(acc);
   reduce_stage_swap<16, true>(acc);
   reduce_stage<8, 4>(acc, lane, 8);
   reduce_stage<4, 4>(acc, lane, 4);
   reduce_stage<2, 4>(acc, lane, 2);
+  const double total = acc[0] + __shfl_xor(acc[0], 1, WAVE);
+  const int idx = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 +
+                  ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+  if ((lane & 1) == 0) s_red[row * NRED + idx] = total;
+}
+
+// Called by ONE wave behind the barrier that follows reduce_wave_to_row: sum of the NROWS rows, solve, update, termination
+// (as gn_level_kernel's tail); the caller closes with a barrier and reads s_ctl[CTL_DONE].
+template <int NROWS>
+__device__ __forceinline__ void sum_rows_solve_update(int lane, const double *s_red, double *s_state, double *s_cst, int *s_ctl,
+                                                      double lambda, int max_iter, double min_grad_norm,
+                                                      int iteration, double &last_gnorm, int &last_valid)
+{
+  static_assert(NROWS % 2 == 0, "the rows are summed in two halves");
+  double v = 0.0;
   {
-    const double total = acc[0] + __shfl_xor(acc[0], 1, WAVE);
-    const int idx = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 +
-                    ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
-    if ((lane & 1) == 0) s_red[wave * NRED + idx] = total;
+    const int j = lane & (NRED - 1);
+    const int w0 = (lane >> 5) * (NROWS / 2);
+#pragma unroll
+    for (int w2 = 0; w2 < NROWS / 2; w2++) v += s_red[(w0 + w2) * NRED + j];
+    v += __shfl_xor(v, 32, WAVE);
   }
+  double h[21], g[6];
+#pragma unroll
+  for (int q = 0; q < 21; q++) h[q] = __shfl(v, q, WAVE);
+#pragma unroll
+  for (int i = 0; i < 6; i++) g[i] = __shfl(v, 21 + i, WAVE);
+  last_valid = (int)__shfl(v, RED_VALID, WAVE);
+  double step[6];
+  solve6_ldlt(h, g, step);
+  double st[6];
+  bool finite = true;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    st[i] = s_state[i] - lambda * step[i];                                            // :539
+    finite = finite && (fabs(st[i]) <= 1.79769313486231570815e308);
+  }
+  double gn2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; i++) gn2 += g[i] * g[i];
+  const double gnorm = sqrt(gn2);                                                     // :380
+  bool done = false;
+  if (iteration + 1 >= max_iter) done = true;                                         // :383
+  else if (gnorm < min_grad_norm) done = true;                                        // :388
+  if (!finite) done = true;
+  if (!done) write_pose_constants(st[0], st[1], st[2], st[3], st[4], st[5], s_cst, lane);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) s_state[i] = st[i];
+    s_ctl[CTL_DONE] = done ? 1 : 0;
+    if (!finite) s_ctl[CTL_FLAGS] |= (int)PHOVO_PAIR_NONFINITE;
+    if (last_valid < 6) s_ctl[CTL_FLAGS] |= (int)PHOVO_PAIR_RANK_DEFICIENT;
+  }
+  last_gnorm = gnorm;
+}
+
+// Wave butterfly + cross-wave sum + solve + update + termination, as in gn_level_kernel's tail, for kernels
+// that keep their 27 sums in `acc` in every wave.  Returns after the closing barrier; the caller reads s_ctl[CTL_DONE].
+template <int NW>
+__device__ __forceinline__ void reduce_solve_update(double (&acc)[NRED], int lane, int wave, double *s_red,
+                                                    double *s_state, double *s_cst, int *s_ctl,
+                                                    double lambda, int max_iter, double min_grad_norm,
+                                                    int iteration, double &last_gnorm, int &last_valid)
+{
+  reduce_wave_to_row(acc, lane, wave, s_red);
   __syncthreads();
-  if (wave == 0) {
-    double v = 0.0;
-    {
-      const int j = lane & (NRED - 1);
-      const int w0 = (lane >> 5) * (NW / 2);
-#pragma unroll
-      for (int w2 = 0; w2 < NW / 2; w2++) v += s_red[(w0 + w2) * NRED + j];
-      v += __shfl_xor(v, 32, WAVE);
-    }
-    double h[21], g[6];
-#pragma unroll
-    for (int q = 0; q < 21; q++) h[q] = __shfl(v, q, WAVE);
-#pragma unroll
-    for (int i = 0; i < 6; i++) g[i] = __shfl(v, 21 + i, WAVE);
-    last_valid = (int)__shfl(v, RED_VALID, WAVE);
-    double step[6];
-    solve6_ldlt(h, g, step);
-    double st[6];
-    bool finite = true;
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-      st[i] = s_state[i] - lambda * step[i];                                            // :539
-      finite = finite && (fabs(st[i]) <= 1.79769313486231570815e308);
-    }
-    double gn2 = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; i++) gn2 += g[i] * g[i];
-    const double gnorm = sqrt(gn2);                                                     // :380
-    bool done = false;
-    if (iteration + 1 >= max_iter) done = true;                                         // :383
-    else if (gnorm < min_grad_norm) done = true;                                        // :388
-    if (!finite) done = true;
-    if (!done) write_pose_constants(st[0], st[1], st[2], st[3], st[4], st[5], s_cst, lane);
-    if (lane == 0) {
-#pragma unroll
-      for (int i = 0; i < 6; i++) s_state[i] = st[i];
-      s_ctl[CTL_DONE] = done ? 1 : 0;
-      if (!finite) s_ctl[CTL_FLAGS] |= (int)PHOVO_PAIR_NONFINITE;
-      if (last_valid < 6) s_ctl[CTL_FLAGS] |= (int)PHOVO_PAIR_RANK_DEFICIENT;
-    }
-    last_gnorm = gnorm;
-  }
+  if (wave == 0)
+    sum_rows_solve_update<NW>(lane, s_red, s_state, s_cst, s_ctl, lambda, max_iter, min_grad_norm, iteration, last_gnorm,
+                              last_valid);
   __syncthreads();
 }
 
