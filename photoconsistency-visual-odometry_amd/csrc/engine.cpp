@@ -1153,7 +1153,9 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
       a.depth_lds_chunks = pl.depth_lds_chunks;
       int *list0 = s.d_handover + (size_t)l * lay.handover_stride;
       int *heads1 = s.d_work_counters + (PHOVO_MAX_LEVELS + l) * QUEUE_HEADS_INTS;
-      if (!pl.owner_in_lds && e->slide_policy >= 0) {
+      // (tuning build: the sliding-window kernel also on levels whose owner map fits LDS, from 160x120 up -- an A/B, profiles/r04_runs)
+      const bool slide_anyway = tuning_switch("PHOVO_SLIDE_FROM_160x120") && lv.n >= 19200 && !few;
+      if ((!pl.owner_in_lds || slide_anyway) && e->slide_policy >= 0) {
         // Owner map too large for LDS: the sliding-window kernel first (owner ring in LDS); pairs whose warp leaves its
         // window are put on the hand-over list and continued, from the iteration they had reached, by the exact kernel
         // right behind it, which draws from that list.
