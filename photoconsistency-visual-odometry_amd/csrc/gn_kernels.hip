@@ -639,7 +639,14 @@ __global__ __launch_bounds__(T, WPS) void gn_fused_kernel(const GNFusedArgs F)
     for (int li = 0; li < F.n_levels; li++) {               // coarse to fine  :502-503
       const GNLevelArgs &A = F.lv[li];
       int iteration = 0, last_valid = 0;
-      level_body<T, false, true, true, TI, TD>(A, L, pair, li > 0, iteration, last_gnorm, last_valid);
+      // A level smaller than the largest leaves the tail of the owner map unused: the depth of its leading chunks is parked
+      // there between the passes (level_body, PARK; gn_launch_fused sizes A.depth_lds_chunks), and the tail gets its -1 back
+      // before the next level may need it as owner map (that level's prologue has the barriers).
+      LevelLds Ll = L;
+      int *const tail = L.owner + owner_lds_entries(A.n, T);
+      Ll.i0 = reinterpret_cast<double *>(tail);
+      level_body<T, false, true, true, TI, TD, true>(A, Ll, pair, li > 0, iteration, last_gnorm, last_valid);
+      for (int k = tid; k < A.depth_lds_chunks * (int)(WAVE * sizeof(double) / sizeof(int)); k += T) tail[k] = -1;
       if (tid == 0 && A.reports) {
         A.reports[pair].iterations[A.level] = iteration;
         A.reports[pair].valid_pixels[A.level] = last_valid;
@@ -851,10 +858,17 @@ hipError_t gn_launch_fused(const GNFusedArgs &f, int storage, int cu_count, hipS
     if (!gn_level_fusable(f.lv[i].n) || f.lv[i].n > f.n_max) return hipErrorInvalidValue;
   const int slots = cu_count * 2;                                              // two 512-thread workgroups per CU
   const int n_blocks = f.n_pairs < slots ? f.n_pairs : slots;
+  // depth parked in the part of the owner map a level does not use (gn_fused_kernel)
+  GNFusedArgs g = f;
+  for (int i = 0; i < g.n_levels; i++) {
+    const int spare = owner_lds_entries(g.n_max, 512) - owner_lds_entries(g.lv[i].n, 512);        // int32 entries
+    const int chunks = (int)((size_t)spare * sizeof(int) / (sizeof(double) * WAVE));
+    g.lv[i].depth_lds_chunks = chunks < g.lv[i].n_chunks ? chunks : g.lv[i].n_chunks;
+  }
   switch (storage) {
-    case PHOVO_STORAGE_F64: return launch_fused_storage<double, double>(f, n_blocks, stream);
-    case PHOVO_STORAGE_F32: return launch_fused_storage<float, float>(f, n_blocks, stream);
-    case PHOVO_STORAGE_F16: return launch_fused_storage<__half, float>(f, n_blocks, stream);
+    case PHOVO_STORAGE_F64: return launch_fused_storage<double, double>(g, n_blocks, stream);
+    case PHOVO_STORAGE_F32: return launch_fused_storage<float, float>(g, n_blocks, stream);
+    case PHOVO_STORAGE_F16: return launch_fused_storage<__half, float>(g, n_blocks, stream);
     default: return hipErrorInvalidValue;
   }
 }
