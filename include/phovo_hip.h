@@ -49,9 +49,10 @@ typedef enum phovo_status {
                                     propagates inf/NaN silently (...Analytic.h:540); so does this
                                     library, but it says so here.                                 */
 #define PHOVO_PAIR_WINDOW_FALLBACK 2u  /* informational: on a level whose owner map exceeds LDS this pair's warp left
-                                    the sliding window of the fast kernel (a displacement of more than ~12 000 pixels in
-                                    linear index, e.g. a large in-plane rotation) and the exact kernel with the map
-                                    in HBM finished it.  The result is the same; only the time differs.          */
+                                    the sliding window of the fast kernel (a displacement of more than about 20 rows of
+                                    the level -- 13 800 pixels in linear index at 640x480, 7 700 at 320x240 -- e.g. a
+                                    large in-plane rotation) and the exact kernel with the map in HBM finished it.  The
+                                    result is the same; only the time differs.                                   */
 #define PHOVO_PAIR_RANK_DEFICIENT 4u  /* fewer than six Jacobian rows were filled in SOME iteration of some level (the
                                     flag is sticky; phovo_pair_report.valid_pixels holds the count of each level's last
                                     iteration): J^T J was singular by construction there and the step taken from it

@@ -488,7 +488,7 @@ int phovo_engine_destroy(phovo_engine *e)
   (void)hipSetDevice(e->device);
   if (e->copy_stream) (void)hipStreamSynchronize(e->copy_stream);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
-  (void)quiesce(e);
+    (void)quiesce(e);
   free_pool(e);
   for (AlignSlot &s : e->slots) {
     free_slot(s);
@@ -526,7 +526,7 @@ int phovo_engine_set_config(phovo_engine *e, const phovo_config *cfg)
   }
   (void)hipSetDevice(e->device);
   (void)hipStreamSynchronize(e->stream);
-  (void)quiesce(e);
+    (void)quiesce(e);
   if (!keep) free_pool(e);
   e->cfg = *cfg;
   return PHOVO_OK;
@@ -558,7 +558,7 @@ int phovo_engine_set_extensions(phovo_engine *e, const phovo_extensions *ext)
   if (ext->plane_storage != e->ext.plane_storage) {      // the pool layout changes
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
-  (void)quiesce(e);
+    (void)quiesce(e);
     free_pool(e);
   }
   e->ext = *ext;
@@ -639,7 +639,7 @@ int phovo_engine_set_build_all_levels(phovo_engine *e, int on)
   if ((on != 0) != e->build_all) {
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
-  (void)quiesce(e);
+    (void)quiesce(e);
     free_pool(e);
   }
   e->build_all = on != 0;
@@ -700,8 +700,9 @@ int phovo_engine_reserve_frames(phovo_engine *e, int n_frames, int width, int he
     if (lv.w < 1 || lv.h < 1) { free_pool(e); return fail(PHOVO_E_SHAPE, "image too small for the number of pyramid levels"); }
     lv.n = lv.w * lv.h;
     lv.stored = e->build_all || e->cfg.max_num_iterations[l] > 0;
-    lv.plan_ok = gn_plan_level(lv.n, &lv.plan);
-    lv.plan_few_ok = gn_plan_level(lv.n, &lv.plan_few, 1);
+    const bool fp64_planes = e->ext.plane_storage == PHOVO_STORAGE_F64;
+    lv.plan_ok = gn_plan_level(lv.n, &lv.plan, 0, fp64_planes);
+    lv.plan_few_ok = gn_plan_level(lv.n, &lv.plan_few, 1, fp64_planes);
     {   // byte layout of one frame at this level: planes I, D, GX, GY.  fp64: packed [4][n] doubles, which is
         // what the producer kernels write directly; narrow storages: every plane starts 16-byte aligned.
       const bool packed = e->ext.plane_storage == PHOVO_STORAGE_F64;
@@ -822,7 +823,7 @@ static int upload_batch(phovo_engine *e, int first_frame, int count, int roles,
   auto drain = [&](int status) {
     (void)hipStreamSynchronize(e->copy_stream);
     (void)hipStreamSynchronize(e->stream);
-  (void)quiesce(e);
+    (void)quiesce(e);
     return status;
   };
 #define PHOVO_UPLOAD_CHECK(expr)                                                                              \

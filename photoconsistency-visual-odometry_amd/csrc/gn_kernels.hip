@@ -692,7 +692,7 @@ enum Variant { V_TINY = 0, V_MID, V_WIDE, V_HUGE, V_QUAD, V_SOLO };
 
 }  // namespace
 
-bool gn_plan_level(int n, GNLaunchPlan *plan, int prefer_latency)
+bool gn_plan_level(int n, GNLaunchPlan *plan, int prefer_latency, bool bound_by_bytes)
 {
   plan->owner_lds_entries = 0;
   plan->mask_in_hbm = false;
@@ -739,9 +739,11 @@ bool gn_plan_level(int n, GNLaunchPlan *plan, int prefer_latency)
     plan->lds_bytes = (int)park_depth(f512 + owner_bytes(512), 2);
     // A level whose owner map fills a half of LDS (160x120: 77 of 80 KB) leaves two workgroups per CU no room to park
     // depth, while ONE workgroup of 1024 threads parks half the image next to the same map: 19.25 -> 18.98 ms per 512 pairs
-    // x 50 iterations of 160x120 (profiles/r04_runs/park_depth_ab.txt).  Throughput launches only.
+    // x 50 iterations of 160x120 (profiles/r04_runs/park_depth_ab.txt).  Throughput launches on fp64 planes only: with the
+    // narrow storages the level is bound by the vector unit, bytes saved buy nothing and one workgroup per CU costs 14 %.
     const bool mid_parks_little = (size_t)plan->depth_lds_chunks * 4 < n_chunks;
-    if (!(mid_parks_little && fits_wide && !prefer_latency && !tuning_switch("PHOVO_GN_NO_WIDE_PARK"))) return true;
+    if (!(mid_parks_little && fits_wide && !prefer_latency && bound_by_bytes && !tuning_switch("PHOVO_GN_NO_WIDE_PARK")))
+      return true;
   }
   if (fits_wide) {
     plan->variant = V_WIDE; plan->threads = 1024; plan->wgs_per_cu = 1; plan->owner_in_lds = true; plan->source_in_lds = false;

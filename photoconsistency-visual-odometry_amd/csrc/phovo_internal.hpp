@@ -84,7 +84,9 @@ struct GNLaunchPlan {
 // Chooses the launch geometry for a level of n pixels.  Returns false if the level cannot be
 // handled (inbound-mask does not fit LDS).
 // prefer_latency 1: the geometry for a handful of pairs (each alone on a CU): 512 threads instead of four workgroups of 256.
-bool gn_plan_level(int n, GNLaunchPlan *plan, int prefer_latency = 0);
+// bound_by_bytes: the planes are fp64 (the level kernels are then bound by bytes at the fabric and a geometry may be chosen
+// for the depth it can park in LDS; with narrow storages they are bound by the vector unit)
+bool gn_plan_level(int n, GNLaunchPlan *plan, int prefer_latency = 0, bool bound_by_bytes = true);
 // args.n_pairs pairs, args.work_counter zeroed on the stream beforehand; the grid is min(pairs, CUs x workgroups/CU).
 hipError_t gn_launch_level(const GNLevelArgs &args, const GNLaunchPlan &plan, int storage, int cu_count,
                            hipStream_t stream);
