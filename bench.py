@@ -140,13 +140,17 @@ def profile_context(kernel, pairs):
             if not (f.startswith(tag + "_") and f.endswith("_pmc_traffic.json")) or "stream_once" in f:
                 continue
             try:
-                for kd in json.load(open(os.path.join(prof, f))).get("kernels", []):
+                # (family, thread count and storage can name two instantiations -- the 1024-thread level kernel with the
+                # owner map in LDS or in HBM: the one with the larger figure is the launch, the other ran behind a
+                # sliding-window launch with few pairs or none)
+                for kd in sorted(json.load(open(os.path.join(prof, f))).get("kernels", []),
+                                 key=lambda k: -k.get("hbm_bytes_per_launch", 0.0)):
                     if same(kd.get("kernel", "")) and kd.get("pairs") == pairs and "traffic" not in out:
                         out["traffic"] = kd["hbm_bytes_per_launch"]
                         out["traffic_source"] = f"profiles/{f} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, calibrated)"
                 sq = os.path.join(prof, f.replace("_pmc_traffic.json", "_pmc_sq.json"))
                 if os.path.exists(sq):
-                    for kd in json.load(open(sq)).get("kernels", []):
+                    for kd in sorted(json.load(open(sq)).get("kernels", []), key=lambda k: -k.get("mean_duration_ns", 0.0)):
                         if same(kd.get("kernel", "")) and kd.get("pairs") == pairs and "valu" not in out:
                             share = kd["fraction_of_wave_cycles"]["issuing VALU (SQ_ACTIVE_INST_VALU)"]
                             waves = kd.get("waves_per_simd", 4)

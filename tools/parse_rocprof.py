@@ -98,7 +98,13 @@ def launch_table(bench, stats_csv, traffic, sq, path):
         row = dict(levels=l["levels"], kernel=l["kernel"], workgroups=l["workgroups"], algorithmic_bytes=l["algorithmic_bytes"],
                    iterations_per_pair=l["iterations_per_pair"], bench_event_ms=l["avg_launch_ms"])
         shared = sum(1 for o in bench["roofline"]["launches"] if o["kernel"] == l["kernel"])
-        for name, (avg, calls) in ns.items():
+        # (two instantiations can share family, thread count and storage -- the 1024-thread level kernel with the owner map
+        # in LDS and the one with the map in HBM that follows a sliding-window launch, usually with no pair to finish: the
+        # launch is the one the trace spent time in)
+        def longest(cands, key):
+            cands = [c for c in cands]
+            return [max(cands, key=key)] if cands else []
+        for name, (avg, calls) in longest([(n_, v) for n_, v in ns.items() if same(n_)], lambda c: c[1][0] * c[1][1]):
             if same(name) and shared == 1:
                 row.update(rocprof_avg_us=avg / 1e3, rocprof_calls=calls,
                            frac_of_8TBs=l["algorithmic_bytes"] / (avg * 1e-9) / 8e12)
@@ -106,11 +112,11 @@ def launch_table(bench, stats_csv, traffic, sq, path):
                 row.update(rocprof_avg_us_over_its_launches=avg / 1e3, rocprof_calls=calls,
                            frac_of_8TBs=l["algorithmic_bytes"] / (l["avg_launch_ms"] * 1e-3) / 8e12,
                            frac_from="bench.py's HIP-event span of this launch")
-        for kd in traffic.get("kernels", []):
+        for kd in longest([k for k in traffic.get("kernels", []) if same(k["kernel"])], lambda k: k["hbm_bytes_per_launch"]):
             if same(kd["kernel"]) and shared == 1:
                 row.update(hbm_bytes_per_launch=kd["hbm_bytes_per_launch"],
                            traffic_over_algorithmic=kd["hbm_bytes_per_launch"] / l["algorithmic_bytes"])
-        for kd in sq or []:
+        for kd in longest([k for k in (sq or []) if same(k["kernel"])], lambda k: k.get("mean_duration_ns", 0.0)):
             if same(kd["kernel"]) and "simd_valu_busy" in kd:
                 row.update(simd_valu_busy=kd["simd_valu_busy"], parked_share=kd["fraction_of_wave_cycles"]["parked (SQ_WAIT_ANY: s_waitcnt / barrier)"],
                            valu_instructions_per_launch=kd["counters"].get("SQ_INSTS_VALU"))
