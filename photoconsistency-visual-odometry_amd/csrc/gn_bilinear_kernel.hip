@@ -148,8 +148,8 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel_bilinear(const GNLevel
         const int r0w = __mul24(max(ir, 0), W), r1w = __mul24(min(ir + 1, H - 1), W);
         if (sizeof(TI) < sizeof(double) && W >= 2) {                      // (compile-time and wave-uniform)
           // Narrow plane storages: the two horizontal taps of a row are neighbours in memory and go out as a PAIR -- one
-          // 8-byte load for two fp32 taps, one address for two fp16 taps (fp32 planes 99 -> 139 k alignments/s, fp16
-          // 110 -> 144 k at 2048 pairs per step).  Not for fp64 planes: a 16-byte gather that is only 8-byte aligned cost
+          // 8-byte load for two fp32 taps, one address for two fp16 taps (fp32 planes 99 -> 176 k alignments/s, fp16
+          // 110 -> 181 k at 8192 pairs per step).  Not for fp64 planes: a 16-byte gather that is only 8-byte aligned cost
           // a quarter of the rate (165 -> 126 k), twelve single loads stay.  In the outer half-pixel band both taps are the
           // edge pixel (clamp to edge): the pair is then loaded one column inside and the edge value copied over the other.
           const int cb = min(max(ic, 0), W - 2);

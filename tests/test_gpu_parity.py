@@ -357,9 +357,41 @@ def test_sliding_window_kernel_matches_exact_kernel_and_oracle(size, iters):
         assert abs(rs[k].gradient_norm - re_[k].gradient_norm) <= 1e-9 * max(1.0, re_[k].gradient_norm)
 
 
+@pytest.mark.parametrize("size", [(232, 172), (64, 700), (1400, 32), (257, 163)])
+def test_sliding_window_on_odd_shapes(size):
+    """Shapes that stress the sliding-window kernel's geometry: a level just above the LDS limit (26 bands of 1536 pixels),
+    a tall strip (m = 4 bands of 24 rows), a flat one (the ring's 10 bands are 11 rows: less than the 16 the host
+    asks for), odd width and height with a partial last chunk.  A pair may leave the window -- the exact kernel then finishes
+    it -- but iteration counts and poses are the oracle's either way, and two runs agree bit for bit."""
+    w, h = size
+    probs = [synthetic.make_pair(180 + i, w, h, holes=0.03, trans=0.004 * (i + 1), rot=0.002 * (i + 1)) for i in range(2)]
+    ncfg, ocfg = _cfgs(1, [4], [0.0])
+    expect = [oracle.align_frames(ocfg, p["K"], p["gray0"], p["depth0"], p["gray1"]) for p in probs]
+    with odometry.AlignmentEngine() as eng:
+        eng.set_config(ncfg)
+        eng.set_intrinsic_matrix(probs[0]["K"])
+        eng.reserve_frames(4, w, h)
+        info = eng.level_launch_info(0)
+        assert not info["owner_in_lds"] and info["threads"] == 768, info
+        for i, p in enumerate(probs):
+            eng.upload_frame(2 * i, p["gray0"], p["depth0"], roles=native.ROLE_SOURCE)
+            eng.upload_frame(2 * i + 1, p["gray1"], None, roles=native.ROLE_TARGET)
+        src = [2 * (k % 2) for k in range(40)]
+        tgt = [2 * (k % 2) + 1 for k in range(40)]
+        s1, r1 = eng.align_pairs(src, tgt, want_reports=True)
+        s2 = eng.align_pairs(src, tgt)
+        assert [r["kind"] for r in eng.last_launches()] == ["slide", "slide_fallback"]
+    assert np.array_equal(s1, s2)
+    for k in range(40):
+        es, eits = expect[k % 2]
+        assert list(r1[k].iterations[:1]) == eits
+        assert r1[k].flags in (0, native.PAIR_WINDOW_FALLBACK), r1[k].flags
+        assert se3.state_distance(s1[k], es) < POSE_TOL
+
+
 def test_sliding_window_hands_large_motions_to_the_exact_kernel():
-    """An in-plane rotation of 0.3 rad moves the pixels at the image border by ~48 rows at 320x240: more than the ring of
-    the sliding-window kernel covers (3 bands of 4096 pixels = 38 rows).  Such pairs must be completed by the exact
+    """An in-plane rotation of 0.3 rad moves the pixels at the image border by ~48 rows at 320x240: more than the window of
+    the sliding-window kernel covers there (5 bands of 1536 pixels = 24 rows behind the source's band, 6 ahead).  Such pairs must be completed by the exact
     kernel, from the iteration at which they left the window, with the reference's result: (a) out of the window from
     the first iteration, (b) drifting out of it after a few iterations, (c) a well-behaved pair in the same launch
     that must not be touched.  48 pairs, mixed."""
