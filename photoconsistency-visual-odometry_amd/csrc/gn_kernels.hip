@@ -338,12 +338,19 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
         o_raw = (kk >= n_lds && kk < n) ? __hip_atomic_load(&g_owner[kk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
       };
       if (!OWNER_LDS) owner_request(k);
-      auto fetch = [&](int kk, auto parked_tag) {      // parked_tag: the chunk's depth was parked in LDS by pass 1
-        o_n = -1;
+      // Owner map in LDS: the entry is read a chunk EARLIER than the rest of the chunk's operands (o_ahead), so that the
+      // gather of the source intensity starts from an index that has already arrived: read in the same fetch it made
+      // every wave wait out an LDS round trip (s_waitcnt lgkmcnt) in front of the five loads of every chunk.
+      int o_ahead = -1;
+      auto fetch = [&](int kk, auto parked_tag, const bool another_behind) {   // parked_tag: the chunk's depth was parked in
+        o_n = -1;                                                              // LDS by pass 1; another_behind: wave-uniform
         if (OWNER_LDS) {
-          if (kk >= 0) {                            // (wave-uniform: walking backwards, the chunk in front of the first)
-            o_n = s_owner[kk];                      // (past the image: the padding, -1)
-            s_owner[kk] = -1;                       // ready for the next iteration
+          o_n = o_ahead;
+          o_ahead = -1;
+          if (another_behind) {                     // (walking backwards: not the chunk in front of the first)
+            const int k2 = kk + k_step;
+            o_ahead = s_owner[k2];                  // (past the image: the padding, -1)
+            s_owner[k2] = -1;                       // ready for the next iteration
           }
         } else {
           if (kk < n_lds) {                         // n_lds is a multiple of 64: the whole chunk is on one side
@@ -362,11 +369,17 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
         if (SRC_LDS) { if (o_n >= 0) i0_n = s_i0[o_n]; }
         else i0_n = plane_load<TI>(rS, o_n, oI);       // :308 of the owning source pixel (o = -1: offset past the plane -> 0)
       };
-      if (PARK && wave + first * NW < depth_chunks) fetch(k, std::true_type{}); else fetch(k, std::false_type{});
-      auto chunk_body = [&](const int chunk, auto next_parked_tag) {
+      if (OWNER_LDS && my_chunks > 0) {
+        o_ahead = s_owner[k];
+        s_owner[k] = -1;
+      }
+      if (PARK && wave + first * NW < depth_chunks) fetch(k, std::true_type{}, my_chunks >= 2);
+      else fetch(k, std::false_type{}, my_chunks >= 2);
+      // `behind`: chunks of this wave that follow the one the body's fetch is for (wave-uniform)
+      auto chunk_body = [&](const int chunk, auto next_parked_tag, const int behind) {
         const int o = o_n;
         const double pz = pz_n, gxi = gx_n, gyi = gy_n, pixel2 = i1_n, pixel1 = i0_n;
-        fetch(k + k_step, next_parked_tag);
+        fetch(k + k_step, next_parked_tag, behind > 0);
         const unsigned long long mbits =
             MASK_REG ? (((unsigned long long)(unsigned)__builtin_amdgcn_readlane(inb_hi, j) << 32) |
                         (unsigned long long)(unsigned)__builtin_amdgcn_readlane(inb_lo, j))
@@ -434,8 +447,8 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
         // positions c_hi .. c_lo of this wave's chunks, downwards; `tag`: is the chunk BEHIND each of them parked?
         auto run = [&](int c_hi, int c_lo, auto tag) {
           for (int c = c_hi; c >= c_lo; c -= 2) {
-            chunk_body(wave + c * NW, tag);
-            if (c > c_lo) chunk_body(wave + (c - 1) * NW, tag);
+            chunk_body(wave + c * NW, tag, c - 1);           // (its fetch is for position c - 1: c - 1 positions follow that)
+            if (c > c_lo) chunk_body(wave + (c - 1) * NW, tag, c - 2);
           }
         };
         if (PARK) {
@@ -450,8 +463,8 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
         }
       } else {
         for (int chunk = wave; chunk < A.n_chunks; chunk += 2 * NW) {
-          chunk_body(chunk, std::false_type{});
-          if (chunk + NW < A.n_chunks) chunk_body(chunk + NW, std::false_type{});
+          chunk_body(chunk, std::false_type{}, 0);
+          if (chunk + NW < A.n_chunks) chunk_body(chunk + NW, std::false_type{}, 0);
         }
       }
     };
