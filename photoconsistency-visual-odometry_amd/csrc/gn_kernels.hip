@@ -329,6 +329,10 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
       // gathered source intensity right behind them) before this chunk's arithmetic starts.
       int o_n = -1;
       double pz_n = 0.0, gx_n = 0.0, gy_n = 0.0, i1_n = 0.0, i0_n = 0.0;
+      // three constants that meet another scalar inside one fma sit in vector registers (an instruction reads one scalar
+      // operand; the compiler otherwise copies them in front of every use: three v_mov_b64 per chunk)
+      double oxv2 = oxi, oyv2 = oyi, cyv2 = cyy;
+      asm volatile("" : "+v"(oxv2), "+v"(oyv2), "+v"(cyv2));
       // Owner map in HBM: the entry is requested TWO chunks ahead (o_raw), so that the gather of the source
       // intensity one chunk ahead starts from an index that has already arrived instead of stalling on it; entries
       // of earlier iterations fail the tag comparison, so nothing is written back (a store per chunk would hold up
@@ -387,8 +391,8 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
         if (__builtin_amdgcn_inverse_ballot_w64(mbits)) {                 // the ballot becomes the exec mask
           const double res = (o >= 0) ? (pixel2 - pixel1) : 0.0;          // :358
           PHOVO_ROWCOL_HERE
-          const double px = fma(cd, ifx, oxi) * pz;
-          const double py = fma(rd, ify, oyi) * pz;
+          const double px = fma(cd, ifx, oxv2) * pz;
+          const double py = fma(rd, ify, oyv2) * pz;
 
           // The 2x6 warp Jacobian (:312-342) contracted with the image gradient (:348), with the common
           // factors pulled out and the reference's temps folded by exact algebraic identities:
@@ -406,7 +410,7 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
           const double Zr = py * t1 + pz * t2 - px * t3;                  // Zd - z
           const double t25 = fast_rcp<1>(cz + Zr);                        // :313  (one Newton step: 2^-48, a Jacobian factor)
           const double Au = pz * t4 + py * t5 + px * t11;
-          const double Bv = fma(py, t6, fma(pz, t9, fma(px, t14, cyy)));
+          const double Bv = fma(py, t6, fma(pz, t9, fma(px, t14, cyv2)));
           const double Cm = -py * t16 - pz * t17 - px * t24;
           const double Dm = py * t2 - pz * t1;
           double J[6];
