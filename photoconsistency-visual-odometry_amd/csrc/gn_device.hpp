@@ -299,6 +299,16 @@ __host__ __device__ __forceinline__ constexpr int owner_lds_entries(int n, int t
   return ((n + 63) & ~63) + threads;
 }
 
+// a * b + c on the 24-bit integer multiplier (full rate; the 32-bit integer multiply takes four times as long): row * width +
+// column of a pixel index.  b is wave-uniform.  (HIP has __mul24 but no mad; behind __mul24 the compiler shifts both terms
+// of the byte address separately -- four instructions where this and one shift-add do.)
+__device__ __forceinline__ int mad24_uniform_b(int a, int b, int c)
+{
+  int r;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+  return r;
+}
+
 // C round() -- half away from zero (...Analytic.h:297-298) -- for arguments > -0.5, which is all the bounds test lets
 // through, in TWO instructions: floor(v + p) with p = 0.49999999999999994, the largest double below one half.  Exact, not
 // approximately right (tests/test_oracle_properties.py checks every neighbour of every tie against exact arithmetic):
