@@ -232,6 +232,9 @@ __global__ __launch_bounds__(T, T / 256) void gn_level_kernel_slide(const GNLeve
       for (int b = 0; b < B2; b++) request(b, k2 + b * STEP);
       __syncthreads();
 
+      // (three constants that meet another scalar inside one fma sit in vector registers, as in gn_kernels.hip)
+      double oxv2 = oxi, oyv2 = oyi, cyv2 = cyy;
+      asm volatile("" : "+v"(oxv2), "+v"(oyv2), "+v"(cyv2));
       auto run_phases = [&](auto huber_tag) {
         constexpr bool HUBER = decltype(huber_tag)::value;
         for (int s = m_run + 1; s < n_phases; s++) {                    // band s - m - 1; wave-uniform trip count
@@ -247,13 +250,13 @@ __global__ __launch_bounds__(T, T / 256) void gn_level_kernel_slide(const GNLeve
             if (__builtin_amdgcn_inverse_ballot_w64(mrow)) {
               const double res = (o >= 0) ? (pixel2 - pixel1) : 0.0;    // :358
               const double rd = trunc(kd2 * inv_w), cd = fma(-rd, dW, kd2);
-              const double px = fma(cd, ifx, oxi) * pz;
-              const double py = fma(rd, ify, oyi) * pz;
+              const double px = fma(cd, ifx, oxv2) * pz;
+              const double py = fma(rd, ify, oyv2) * pz;
               // factored Jacobian, derivation in gn_kernels.hip (pass 2)
               const double Zr = py * t1 + pz * t2 - px * t3;
               const double t25 = fast_rcp<1>(cz + Zr);                  // :313
               const double Au = pz * t4 + py * t5 + px * t11;           // temp11 = temp15 + x: the reference's slip (:253), kept
-              const double Bv = fma(py, t6, fma(pz, t9, fma(px, t14, cyy)));
+              const double Bv = fma(py, t6, fma(pz, t9, fma(px, t14, cyv2)));
               const double Cm = -py * t16 - pz * t17 - px * t24;
               const double Dm = py * t2 - pz * t1;
               double J[6];
