@@ -299,9 +299,10 @@ __host__ __device__ __forceinline__ constexpr int owner_lds_entries(int n, int t
   return ((n + 63) & ~63) + threads;
 }
 
-// a * b + c on the 24-bit integer multiplier (full rate; the 32-bit integer multiply takes four times as long): row * width +
-// column of a pixel index.  b is wave-uniform.  (HIP has __mul24 but no mad; behind __mul24 the compiler shifts both terms
-// of the byte address separately -- four instructions where this and one shift-add do.)
+// a * b + c as ONE instruction on the 24-bit integer multiplier: row * width + column of a pixel index.  b is wave-uniform.
+// What it saves is instructions, not a slow multiply (v_mul_lo_u32 issues at full rate on gfx950,
+// profiles/r04_runs/valu_rate_probe.txt): written as row * W + column the compiler distributes the shift of the byte
+// address over both terms -- multiply, two shifts, add3 -- where this and one shift-add do.  (HIP has __mul24 but no mad.)
 __device__ __forceinline__ int mad24_uniform_b(int a, int b, int c)
 {
   int r;

@@ -216,7 +216,7 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
             __builtin_amdgcn_ballot_w64(ri < H) & __builtin_amdgcn_ballot_w64(tc > -0.5) &
             __builtin_amdgcn_ballot_w64(ci < W);
         m_out = m;
-        t_out = mad24_uniform_b(ri, W, ci);           // (24-bit multiply-add: full rate; the 32-bit integer multiply takes four times as long)
+        t_out = mad24_uniform_b(ri, W, ci);           // (one multiply-add + one shift-add to the LDS address: gn_device.hpp)
       };
       auto keep_mask = [&](const unsigned long long m, const int chunk) {
         if (!MASK_REG) n_rows += __builtin_popcountll(m);

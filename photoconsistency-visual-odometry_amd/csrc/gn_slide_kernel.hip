@@ -173,7 +173,7 @@ __global__ __launch_bounds__(T, T / 256) void gn_level_kernel_slide(const GNLeve
               in_image & __builtin_amdgcn_ballot_w64(min_d < pz) & __builtin_amdgcn_ballot_w64(pz < max_d) &
               __builtin_amdgcn_ballot_w64(tr > -0.5) & __builtin_amdgcn_ballot_w64(ri < H) &
               __builtin_amdgcn_ballot_w64(tc > -0.5) & __builtin_amdgcn_ballot_w64(ci < W);          // :280, :302-303
-          const int t = mad24_uniform_b(ri, W, ci);                           // (24-bit multiply-add: full rate)
+          const int t = mad24_uniform_b(ri, W, ci);                           // (gn_device.hpp)
           // inside the window of this phase?  (unsigned compare: below win_lo wraps to a huge value)
           const unsigned long long inside = __builtin_amdgcn_ballot_w64((unsigned)(t - win_lo) < win_span);
           if (m & ~inside) {                                            // wave-uniform, rare: this iteration is void
