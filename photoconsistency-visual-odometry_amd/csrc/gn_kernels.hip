@@ -143,7 +143,19 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
 #define PHOVO_ROWCOL_HERE { rd = trunc(kd * inv_w); cd = fma(-rd, dW, kd); }
 #define PHOVO_ROWCOL_NEXT kd += kd_step;
 
+#ifdef PHOVO_PHASE_STAMPS
+  // Diagnostic build only (make ... EXTRA=-DPHOVO_PHASE_STAMPS): where the iterations of ONE pair spend their time, per wave,
+  // in ticks of the 100 MHz wall clock: pass 1, the barrier behind it, pass 2, the butterfly, the barrier in front of the
+  // solve, the solve (wave 0) or the wait for it.  Printed by workgroup 0 for the first pair it draws.
+  unsigned long long stamp_sum[6] = {0, 0, 0, 0, 0, 0}, stamp_last = wall_clock64();
+#define PHOVO_STAMP(i) { const unsigned long long t_ = wall_clock64(); stamp_sum[i] += t_ - stamp_last; stamp_last = t_; }
+#else
+#define PHOVO_STAMP(i)
+#endif
   while (true) {
+#ifdef PHOVO_PHASE_STAMPS
+    stamp_last = wall_clock64();
+#endif
     // ---- constants of this iteration (uniform -> SGPRs) -----------------------------------
     const double cx = uniform_f64(s_cst[C_X]), cyy = uniform_f64(s_cst[C_Y]), cz = uniform_f64(s_cst[C_Z]);
     const double r01 = uniform_f64(s_cst[C_R01]), r02 = uniform_f64(s_cst[C_R02]);
@@ -297,7 +309,9 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
         }
       }
     }
+    PHOVO_STAMP(0)
     __syncthreads();
+    PHOVO_STAMP(1)
 
     // ---- pass 2: residual, Jacobian row, normal-equation accumulation ---------------------
     const double t4 = uniform_f64(s_cst[C_T4]), t5 = uniform_f64(s_cst[C_T5]), t6 = uniform_f64(s_cst[C_T6]);
@@ -473,6 +487,7 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
       }
     };
     if (huber_on) pass2(std::true_type{}); else pass2(std::false_type{});
+    PHOVO_STAMP(2)
     // The number of Jacobian rows filled rides through the reduction in a spare slot.  MASK_REG: lane j still holds chunk
     // j's ballot -- its popcount is that chunk's rows, and the sum over lanes and waves is the pair's (three vector
     // instructions per iteration instead of two scalar ones per chunk).
@@ -495,7 +510,9 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
       const int idx = ((ln >> 5) & 1) * 16 + ((ln >> 4) & 1) * 8 + ((ln >> 3) & 1) * 4 + ((ln >> 2) & 1) * 2 + ((ln >> 1) & 1);
       if ((ln & 1) == 0) s_red[wave * NRED + idx] = total;
     }
+    PHOVO_STAMP(3)
     __syncthreads();
+    PHOVO_STAMP(4)
 
     // ---- wave 0: cross-wave sum (fixed order), solve, update, terminate ------------------------
     if (wave == 0) {
@@ -546,9 +563,16 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
       last_gnorm = gnorm;
     }
     __syncthreads();
+    PHOVO_STAMP(5)
     iteration++;
     if (s_ctl[CTL_DONE]) break;
   }
+#ifdef PHOVO_PHASE_STAMPS
+  if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 1 || wave == NW / 2 || wave == NW - 1))
+    printf("stamps T=%d level n=%d it=%d wave %2d: pass1 %llu barrier %llu pass2 %llu butterfly %llu barrier %llu solve/wait %llu (10 ns ticks)\n",
+           T, n, iteration, wave, stamp_sum[0], stamp_sum[1], stamp_sum[2], stamp_sum[3], stamp_sum[4], stamp_sum[5]);
+#endif
+#undef PHOVO_STAMP
 #undef PHOVO_ROWCOL_BEGIN
 #undef PHOVO_ROWCOL_HERE
 #undef PHOVO_ROWCOL_NEXT
