@@ -70,6 +70,9 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
                                            int &iteration, double &last_gnorm, int &last_valid)
 {
   constexpr int NW = T / WAVE;
+#ifdef PHOVO_PHASE_STAMPS
+  const unsigned long long stamp_entry = wall_clock64();
+#endif
   double *const s_cst = L.cst, *const s_state = L.state, *const s_red = L.red, *const s_i0 = L.i0;
   int *const s_ctl = L.ctl, *const s_owner = L.owner;
   // (ballots in global memory: written and read back by the same wave, chunk by chunk -- program order is all it needs)
@@ -148,6 +151,7 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
   // in ticks of the 100 MHz wall clock: pass 1, the barrier behind it, pass 2, the butterfly, the barrier in front of the
   // solve, the solve (wave 0) or the wait for it.  Printed by workgroup 0 for the first pair it draws.
   unsigned long long stamp_sum[6] = {0, 0, 0, 0, 0, 0}, stamp_last = wall_clock64();
+  const unsigned long long stamp_prologue = stamp_last - stamp_entry;
 #define PHOVO_STAMP(i) { const unsigned long long t_ = wall_clock64(); stamp_sum[i] += t_ - stamp_last; stamp_last = t_; }
 #else
 #define PHOVO_STAMP(i)
@@ -569,8 +573,8 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
   }
 #ifdef PHOVO_PHASE_STAMPS
   if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 1 || wave == NW / 2 || wave == NW - 1))
-    printf("stamps T=%d level n=%d it=%d wave %2d: pass1 %llu barrier %llu pass2 %llu butterfly %llu barrier %llu solve/wait %llu (10 ns ticks)\n",
-           T, n, iteration, wave, stamp_sum[0], stamp_sum[1], stamp_sum[2], stamp_sum[3], stamp_sum[4], stamp_sum[5]);
+    printf("stamps T=%d level n=%d it=%d wave %2d: pass1 %llu barrier %llu pass2 %llu butterfly %llu barrier %llu solve/wait %llu prologue %llu (10 ns ticks)\n",
+           T, n, iteration, wave, stamp_sum[0], stamp_sum[1], stamp_sum[2], stamp_sum[3], stamp_sum[4], stamp_sum[5], stamp_prologue);
 #endif
 #undef PHOVO_STAMP
 #undef PHOVO_ROWCOL_BEGIN

@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
 """Where one pair's iterations spend their time inside the level kernels (diagnostic build of the library):
     make -C photoconsistency-visual-odometry_amd/csrc EXTRA=-DPHOVO_PHASE_STAMPS BUILD=/tmp/build_stamps OUT=$PWD/photoconsistency-visual-odometry_amd/libphovo_hip_stamps.so
-    PHOVO_HIP_LIBRARY=photoconsistency-visual-odometry_amd/libphovo_hip_stamps.so python3 tools/phase_stamps.py [pairs]
+    PHOVO_HIP_LIBRARY=photoconsistency-visual-odometry_amd/libphovo_hip_stamps.so python3 tools/phase_stamps.py [pairs [shipped]]
 Workgroup 0 prints, for every pair it draws and four of its waves, the 10 ns ticks spent in pass 1, at the barrier behind it,
 in pass 2, in the butterfly, at the barrier in front of the solve and in / waiting for the solve (csrc/gn_kernels.hip,
-PHOVO_STAMP).  Fixed-iteration mode of the 4-level configuration: 50 iterations at 80x60, 20 at 160x120."""
+PHOVO_STAMP).  Fixed-iteration mode of the 4-level configuration: 50 iterations at 80x60, 20 at 160x120.  (The printing
+workgroup is slowed by its own printf round trips and draws fewer pairs than the others; with the shipped thresholds its
+later pairs run at the tail of the batch, next to an idle neighbour -- read the fixed-iteration figures, where every pair of
+a workgroup sees the same load.)"""
 import os
 import sys
 
@@ -15,8 +18,10 @@ from phovo_amd import native, odometry, synthetic  # noqa: E402
 n_pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 cfg = native.read_config_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "config_files",
                                           "config_4_level_optimization_analytic.yml"))
-for l in range(cfg.num_levels):
-    cfg.min_gradient_norm[l] = 0.0
+shipped = len(sys.argv) > 2 and sys.argv[2] == "shipped"      # keep the yml's gradient thresholds: the fused launch
+if not shipped:
+    for l in range(cfg.num_levels):
+        cfg.min_gradient_norm[l] = 0.0
 pairs = [synthetic.make_pair(i, 640, 480) for i in range(8)]
 with odometry.AlignmentEngine() as eng:
     eng.set_config(cfg)
