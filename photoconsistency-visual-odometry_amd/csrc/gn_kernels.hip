@@ -152,6 +152,7 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
   // solve, the solve (wave 0) or the wait for it.  Printed by workgroup 0 for the first pair it draws.
   unsigned long long stamp_sum[6] = {0, 0, 0, 0, 0, 0}, stamp_last = wall_clock64();
   const unsigned long long stamp_prologue = stamp_last - stamp_entry;
+  unsigned long long solve_sum[4] = {0, 0, 0, 0};
 #define PHOVO_STAMP(i) { const unsigned long long t_ = wall_clock64(); stamp_sum[i] += t_ - stamp_last; stamp_last = t_; }
 #else
 #define PHOVO_STAMP(i)
@@ -538,8 +539,18 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
       for (int i = 0; i < 6; i++) g[i] = __shfl(v, 21 + i, WAVE);
 
       last_valid = (int)__shfl(v, RED_VALID, WAVE);
+#ifdef PHOVO_PHASE_STAMPS
+      asm volatile("" :: "v"(h[0]), "v"(g[5]));
+      const unsigned long long solve_t0 = wall_clock64();
+#endif
       double step[6];
       solve6_ldlt(h, g, step);
+#ifdef PHOVO_PHASE_STAMPS
+      asm volatile("" :: "v"(step[0]), "v"(step[5]));
+      const unsigned long long solve_t1 = wall_clock64();
+      solve_sum[0] += solve_t0 - stamp_last;       // cross-wave sum and broadcasts
+      solve_sum[1] += solve_t1 - solve_t0;         // LDL^T
+#endif
       double st[6];
       bool finite = true;
 #pragma unroll
@@ -556,7 +567,16 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
       if (it >= A.max_iter) done = true;                                                // :383
       else if (gnorm < A.min_grad_norm) done = true;                                    // :388
       if (!finite) done = true;     // the reference would keep iterating on NaN; the result is the same NaN
+#ifdef PHOVO_PHASE_STAMPS
+      asm volatile("" :: "v"(gnorm));
+      const unsigned long long solve_t2 = wall_clock64();
+      solve_sum[2] += solve_t2 - solve_t1;         // update, norm, termination
+#endif
       if (!done) write_pose_constants(st[0], st[1], st[2], st[3], st[4], st[5], s_cst, lane);   // wave-uniform branch
+#ifdef PHOVO_PHASE_STAMPS
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      solve_sum[3] += wall_clock64() - solve_t2;   // sincos and pose constants
+#endif
       if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < 6; i++) s_state[i] = st[i];
@@ -575,6 +595,9 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
   if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 1 || wave == NW / 2 || wave == NW - 1))
     printf("stamps T=%d level n=%d it=%d wave %2d: pass1 %llu barrier %llu pass2 %llu butterfly %llu barrier %llu solve/wait %llu prologue %llu (10 ns ticks)\n",
            T, n, iteration, wave, stamp_sum[0], stamp_sum[1], stamp_sum[2], stamp_sum[3], stamp_sum[4], stamp_sum[5], stamp_prologue);
+  if (blockIdx.x == 0 && lane == 0 && wave == 0)
+    printf("stamps T=%d level n=%d it=%d inside wave 0's serial section: row sums %llu  LDL^T %llu  update+norm %llu  pose constants %llu\n",
+           T, n, iteration, solve_sum[0], solve_sum[1], solve_sum[2], solve_sum[3]);
 #endif
 #undef PHOVO_STAMP
 #undef PHOVO_ROWCOL_BEGIN
