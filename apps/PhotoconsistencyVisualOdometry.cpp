@@ -35,6 +35,7 @@
 
 #include "io/png_io.h"
 #include "rccl/rccl_gather.h"
+#include "rccl/shard_vote.h"
 #include "phovo/CPhotoconsistencyOdometryAnalytic.h"
 
 typedef double CoordinateType;
@@ -261,37 +262,55 @@ int main(int argc, char *argv[])
         if (!group.create(devices, &err)) { std::cerr << err << std::endl; return EXIT_FAILURE; }
       }
       const auto t0 = std::chrono::steady_clock::now();
+      // Every shard thread arrives at the vote exactly once -- also one that failed on its way there, and one whose range
+      // is empty -- and the collective is entered only if all of them are ready for it: a rank that stays away from an
+      // all_gather leaves the others waiting in it for ever.
+      phovo_rccl::ShardVote vote(nGpus);
+      // test hook: shard N reports a failure before it touches its device (tests: the run must end with that error, not hang)
+      const int injectFailure = std::getenv("PHOVO_VO_INJECT_SHARD_FAILURE") ? std::atoi(std::getenv("PHOVO_VO_INJECT_SHARD_FAILURE")) : -1;
       auto alignShard = [&](int g) {
         const int base = nPairs / nGpus, extra = nPairs % nGpus;
         const int a = g * base + (g < extra ? g : extra), b = a + base + (g < extra ? 1 : 0);
-        if (b <= a) return;
         const int f0 = a, nf = b - a + 1;
         phovo_engine *engine = nullptr;
-        auto fail = [&](const char *what) { shardError[g] = std::string(what) + ": " + phovo_last_error(); if (engine) phovo_engine_destroy(engine); };
-        if (phovo_engine_create(g % nDevices, &engine) != PHOVO_OK) return fail("phovo_engine_create");
-        if (phovo_engine_set_config(engine, &cfg) != PHOVO_OK) return fail("phovo_engine_set_config");
-        // a pair's pose must not depend on the size of the shard it falls into (same trajectory file for every N)
-        if (phovo_engine_set_batch_invariant(engine, 1) != PHOVO_OK) return fail("phovo_engine_set_batch_invariant");
-        if (phovo_engine_set_intrinsic_matrix(engine, intrinsicMatrix.data()) != PHOVO_OK) return fail("phovo_engine_set_intrinsic_matrix");
-        if (phovo_engine_reserve_frames(engine, nf, W, H) != PHOVO_OK) return fail("phovo_engine_reserve_frames");
-        if (phovo_engine_upload_frames_u16(engine, 0, nf, PHOVO_ROLE_BOTH, allGray.data() + (size_t)W * H * f0, (size_t)W,
-                                           (size_t)W * H, allDepth.data() + (size_t)W * H * f0, sizeof(uint16_t) * (size_t)W,
-                                           sizeof(uint16_t) * (size_t)W * H, depthScalingFactor) != PHOVO_OK)
-          return fail("phovo_engine_upload_frames_u16");
-        std::vector<int> src(b - a), tgt(b - a);
-        for (int p = 0; p < b - a; p++) { src[p] = p; tgt[p] = p + 1; }
-        if (!rccl) {
-          if (phovo_engine_align_pairs(engine, b - a, src.data(), tgt.data(), nullptr, states.data() + (size_t)a * 6, nullptr) != PHOVO_OK)
-            return fail("phovo_engine_align_pairs");
-        } else {
-          void *dStates = nullptr;
+        void *dStates = nullptr;
+        auto work = [&]() -> bool {                       // everything of this shard short of the collective
+          auto fail = [&](const char *what) { shardError[g] = std::string(what) + ": " + phovo_last_error(); return false; };
+          if (b <= a) return true;                        // more shards than pairs: nothing to align, still a rank of the gather
+          if (injectFailure == g) { shardError[g] = "shard " + std::to_string(g) + ": failure injected (PHOVO_VO_INJECT_SHARD_FAILURE)"; return false; }
+          if (phovo_engine_create(g % nDevices, &engine) != PHOVO_OK) return fail("phovo_engine_create");
+          if (phovo_engine_set_config(engine, &cfg) != PHOVO_OK) return fail("phovo_engine_set_config");
+          // a pair's pose must not depend on the size of the shard it falls into (same trajectory file for every N)
+          if (phovo_engine_set_batch_invariant(engine, 1) != PHOVO_OK) return fail("phovo_engine_set_batch_invariant");
+          if (phovo_engine_set_intrinsic_matrix(engine, intrinsicMatrix.data()) != PHOVO_OK) return fail("phovo_engine_set_intrinsic_matrix");
+          if (phovo_engine_reserve_frames(engine, nf, W, H) != PHOVO_OK) return fail("phovo_engine_reserve_frames");
+          if (phovo_engine_upload_frames_u16(engine, 0, nf, PHOVO_ROLE_BOTH, allGray.data() + (size_t)W * H * f0, (size_t)W,
+                                             (size_t)W * H, allDepth.data() + (size_t)W * H * f0, sizeof(uint16_t) * (size_t)W,
+                                             sizeof(uint16_t) * (size_t)W * H, depthScalingFactor) != PHOVO_OK)
+            return fail("phovo_engine_upload_frames_u16");
+          std::vector<int> src(b - a), tgt(b - a);
+          for (int p = 0; p < b - a; p++) { src[p] = p; tgt[p] = p + 1; }
+          if (!rccl) {
+            if (phovo_engine_align_pairs(engine, b - a, src.data(), tgt.data(), nullptr, states.data() + (size_t)a * 6, nullptr) != PHOVO_OK)
+              return fail("phovo_engine_align_pairs");
+            return true;
+          }
           if (phovo_engine_enqueue_align(engine, b - a, src.data(), tgt.data(), nullptr) != PHOVO_OK) return fail("phovo_engine_enqueue_align");
           if (phovo_engine_synchronize(engine) != PHOVO_OK) return fail("phovo_engine_synchronize");
           if (phovo_engine_results_device_ptr(engine, &dStates) != PHOVO_OK) return fail("phovo_engine_results_device_ptr");
+          return true;
+        };
+        bool ok = work();
+        if (rccl) {
           std::string err;
-          if (!group.all_gather_states(g, dStates, b - a, maxShard, &err)) { shardError[g] = err; phovo_engine_destroy(engine); return; }
+          if (ok && !group.stage(g, dStates, b > a ? b - a : 0, maxShard, &err)) { shardError[g] = err; ok = false; }
+          if (vote.arrive(ok)) {                          // every rank is staged: all of them enter the collective
+            if (!group.gather(g, &err)) shardError[g] = err;
+          } else if (ok) {
+            shardError[g] = "";                           // (another shard failed and says so; this one just stays out)
+          }
         }
-        phovo_engine_destroy(engine);
+        if (engine) phovo_engine_destroy(engine);
       };
       {
         std::vector<std::thread> shards;

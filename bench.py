@@ -56,7 +56,11 @@ def parse():
     ap.add_argument("--pairs", type=int, default=None,
                     help="frame pairs per GPU per step (a level launch has ~0.13 ms of fixed cost: 2048 pairs run at "
                          "241 k alignments/s, 8192 at 253 k, 16384 at 254 k)")
-    ap.add_argument("--distinct", type=int, default=32, help="distinct synthetic pairs generated per GPU")
+    ap.add_argument("--distinct", type=int, default=1024,
+                    help="distinct synthetic pairs generated per GPU (consecutive frames of one rendered sequence; the batch "
+                         "repeats them, every repeat with its own copy of the planes in HBM).  The fixed-iteration headline "
+                         "does not depend on it (profiles/r04_runs/distinct_pairs.txt: 32 ... 4096); with the shipped "
+                         "thresholds the iteration counts are data, and 32 pairs are not a sample of them")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="bound of the CPU-oracle baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="threads of the all-cores CPU baseline (a one-GPU box's CPU share); 1 = skip it")
@@ -121,10 +125,22 @@ def launch_rows(launches, per_level_ms, steps, iters, level_sizes, plane_bytes, 
     return rows
 
 
+def library_sha256():
+    """sha256 of the libphovo_hip.so this process loaded: a stored profile is this build's only if it carries the same one."""
+    import hashlib
+    h = hashlib.sha256()
+    with open(native.library_path(), "rb") as f:
+        for block in iter(lambda: f.read(1 << 20), b""):
+            h.update(block)
+    return h.hexdigest()
+
+
 def profile_context(kernel, pairs):
     """What the committed rocprofv3 counter passes (profiles/, newest round first) hold for `kernel` (the name form of
     launch_rows) at `pairs` pairs per launch: HBM-side bytes per launch, vector-unit busy fraction and vector instructions
-    per launch, and the rate at which the same kernel streams planes it reads exactly once (pure HBM)."""
+    per launch, and the rate at which the same kernel streams planes it reads exactly once (pure HBM).  These are NOT
+    measurements of the running process (PMC passes cannot run inside it): every profile JSON carries the sha256 of the
+    library it was collected on (tools/parse_rocprof.py), and `library_matches` says whether that is the library loaded now."""
     import csv
     import re
     out = {}
@@ -135,7 +151,7 @@ def profile_context(kernel, pairs):
         return bool(m) and m.group(1) == fam and int(m.group(2)) == int(threads) and types in name
 
     prof = os.path.join(ROOT, "profiles")
-    for tag in ("r04", "r03"):
+    for tag in ("r05", "r04", "r03"):
         for f in sorted(os.listdir(prof)):
             if not (f.startswith(tag + "_") and f.endswith("_pmc_traffic.json")) or "stream_once" in f:
                 continue
@@ -143,11 +159,13 @@ def profile_context(kernel, pairs):
                 # (family, thread count and storage can name two instantiations -- the 1024-thread level kernel with the
                 # owner map in LDS or in HBM: the one with the larger figure is the launch, the other ran behind a
                 # sliding-window launch with few pairs or none)
-                for kd in sorted(json.load(open(os.path.join(prof, f))).get("kernels", []),
-                                 key=lambda k: -k.get("hbm_bytes_per_launch", 0.0)):
+                doc = json.load(open(os.path.join(prof, f)))
+                for kd in sorted(doc.get("kernels", []), key=lambda k: -k.get("hbm_bytes_per_launch", 0.0)):
                     if same(kd.get("kernel", "")) and kd.get("pairs") == pairs and "traffic" not in out:
                         out["traffic"] = kd["hbm_bytes_per_launch"]
                         out["traffic_source"] = f"profiles/{f} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, calibrated)"
+                        out["profile_library_sha256"] = doc.get("library_sha256")
+                        out["profile_commit"] = doc.get("commit")
                 sq = os.path.join(prof, f.replace("_pmc_traffic.json", "_pmc_sq.json"))
                 if os.path.exists(sq):
                     for kd in sorted(json.load(open(sq)).get("kernels", []), key=lambda k: -k.get("mean_duration_ns", 0.0)):
@@ -203,6 +221,7 @@ def run_steps(eng, src, tgt, steps, use_dist, device, n_global, pipelined=False)
     results of every step are still gathered, one step behind.  The per-enqueue event spans then overlap and are not summed
     into anything: with pipelined=True only the wall time is meaningful."""
     per_level = np.zeros(native.MAX_LEVELS + 1)          # [level spans ..., whole enqueue]
+    STEP_WALL.clear()                                    # wall time of every step of this call (min / median / max in the line)
 
     def finish(ticket):
         eng.wait(ticket)
@@ -218,6 +237,7 @@ def run_steps(eng, src, tgt, steps, use_dist, device, n_global, pipelined=False)
 
     t0 = time.perf_counter()
     pending = None
+    t_step = t0
     for _ in range(steps):
         eng.enqueue_align(src, tgt)
         ticket = eng.last_ticket()
@@ -227,9 +247,24 @@ def run_steps(eng, src, tgt, steps, use_dist, device, n_global, pipelined=False)
             pending = ticket
         else:
             finish(ticket)
+        t_now = time.perf_counter()
+        STEP_WALL.append(t_now - t_step)
+        t_step = t_now
     if pending is not None:
         finish(pending)
     return time.perf_counter() - t0, per_level
+
+
+STEP_WALL = []
+
+
+def step_wall_summary():
+    """min / median / max wall time of the steps of the last run_steps() call (one enqueue at a time: a step is enqueue +
+    wait + gather; pipelined: the interval between two enqueues), so that a reader sees whether the timed region was steady."""
+    if not STEP_WALL:
+        return None
+    a = np.array(STEP_WALL) * 1e3
+    return dict(min=float(a.min()), median=float(np.median(a)), max=float(a.max()), steps=int(a.size))
 
 
 def launch_ranks(args):
@@ -323,7 +358,8 @@ def main():
 
     # ---- synthetic inputs: one sequence per rank, `distinct` pairs, replicated to `pairs` slots ----
     distinct = max(1, min(args.distinct, args.pairs))
-    seq = synthetic.make_sequence(seed=100 + rank, n_frames=distinct + 1, width=W, height=H, holes=0.01, scene=args.scene)
+    seq = synthetic.make_sequence(seed=100 + rank, n_frames=distinct + 1, width=W, height=H, holes=0.01, scene=args.scene,
+                                  workers=min(16, os.cpu_count() or 1))
     reps = (args.pairs + distinct - 1) // distinct
     cfg_ref = native.read_config_file(YML)
     nl = cfg_ref.num_levels
@@ -362,7 +398,9 @@ def main():
         for t in range(distinct):
             src.append(base + t)
             tgt.append(base + t + 1)
-    src, tgt = src[:args.pairs], tgt[:args.pairs]
+    # (int32 arrays: what the C ABI takes; as Python lists the two conversions cost 0.3 ms of host time per step, which in a
+    # one-enqueue-at-a-time loop is 1 % of a fixed-iteration step and 6 % of one with the shipped thresholds)
+    src, tgt = np.array(src[:args.pairs], dtype=np.int32), np.array(tgt[:args.pairs], dtype=np.int32)
     n_local = len(src)
     n_global = n_local * world
     level_sizes = [eng.level_size(l)[0] * eng.level_size(l)[1] for l in range(nl)]
@@ -390,6 +428,7 @@ def main():
         wall, _ = run_steps(eng, src, tgt, args.steps, use_dist, device, n_global, pipelined=True)
     else:
         wall, per_level_ms = run_steps(eng, src, tgt, args.steps, use_dist, device, n_global)
+    step_wall_ms = step_wall_summary()
     barrier()
     if use_dist:
         tmax = torch.tensor([wall], dtype=torch.float64, device=device)
@@ -418,27 +457,42 @@ def main():
                     launches=levels_out)
     # What the PMC counters say about that kernel: collected in separate rocprofv3 --pmc passes of this same command
     # (profiles/README.md; they cannot be measured from inside the run) -- HBM-side traffic per launch (FETCH_SIZE + WRITE_SIZE,
-    # calibrated) and how busy the vector units are (SQ_ACTIVE_INST_VALU).  `bound` names whichever of the two is nearer
-    # saturation: this path's arithmetic is fp64 on the vector unit, and with narrow plane storages or few re-reads from HBM
-    # that unit, not the memory system, is what the kernel waits for.
+    # calibrated) and how busy the vector units are (SQ_ACTIVE_INST_VALU).  `bound` stays "hbm", the roofline SURVEY.md 8(d)
+    # prices the path against; which of the two limits the stored counters show nearer saturation is said in
+    # from_stored_profile.nearer_saturated (this path's arithmetic is fp64 on the vector unit: with narrow plane storages or
+    # few re-reads from HBM that unit, not the memory system, is what the kernel waits for).
     plain_mode = args.huber == 0.0 and not args.bilinear      # the counters were collected on the reference path
     ctx = profile_context(dom["kernel"], n_local if plain_mode or args.bilinear else -1)
-    if ctx.get("traffic") is not None:
-        roofline["traffic"] = ctx["traffic"]
-        roofline["traffic_over_algorithmic"] = ctx["traffic"] / dom["algorithmic_bytes"]
-        roofline["traffic_GBs"] = ctx["traffic"] / (dom["avg_launch_ms"] * 1e-3) / 1e9
-        roofline["traffic_source"] = ctx["traffic_source"]
-    if ctx.get("valu") is not None:
-        v = dict(ctx["valu"])
-        chunk_iterations = sum(dom["pair_iterations_per_level"][str(l)] * ((level_sizes[l] + 63) // 64) for l in dom["levels"])
-        if v.get("instructions_per_launch") and chunk_iterations > 0:
-            v["wave_instructions_per_64_pixel_iteration"] = v["instructions_per_launch"] / chunk_iterations
-        roofline["valu"] = v
-        mem_sat = roofline.get("traffic_GBs", dom["achieved_GBs"]) / HBM_PEAK_GBS
-        roofline["saturation"] = {"hbm_side_traffic_over_peak": mem_sat, "vector_unit_busy": v["busy"]}
-        roofline["bound"] = "valu" if v["busy"] > mem_sat else "hbm"
-    if ctx.get("hbm_stream_measured") is not None:
-        roofline["hbm_stream_measured"] = ctx["hbm_stream_measured"]
+    # Everything below comes from profiles/ -- another run, maybe another box -- and is kept apart under its own name;
+    # `traffic` (the contract's field) is filled from it only when the profile was collected on THIS build of the library.
+    stored = None
+    if ctx:
+        lib_sha = library_sha256()
+        same_build = ctx.get("profile_library_sha256") == lib_sha
+        stored = dict(note="read from committed rocprofv3 counter passes (profiles/), NOT measured in this run; the "
+                           "*_with_this_runs_duration figures divide the stored bytes by this run's launch duration",
+                      library_sha256_of_profile=ctx.get("profile_library_sha256"), commit_of_profile=ctx.get("profile_commit"),
+                      library_sha256_loaded=lib_sha, same_build_as_loaded_library=bool(same_build))
+        if ctx.get("traffic") is not None:
+            stored["traffic"] = ctx["traffic"]
+            stored["traffic_source"] = ctx["traffic_source"]
+            stored["traffic_over_algorithmic"] = ctx["traffic"] / dom["algorithmic_bytes"]
+            stored["traffic_GBs_with_this_runs_duration"] = ctx["traffic"] / (dom["avg_launch_ms"] * 1e-3) / 1e9
+            if same_build:
+                roofline["traffic"] = ctx["traffic"]
+                roofline["traffic_source"] = ctx["traffic_source"] + " -- same library build as this run, other process"
+        if ctx.get("valu") is not None:
+            v = dict(ctx["valu"])
+            chunk_iterations = sum(dom["pair_iterations_per_level"][str(l)] * ((level_sizes[l] + 63) // 64) for l in dom["levels"])
+            if v.get("instructions_per_launch") and chunk_iterations > 0:
+                v["wave_instructions_per_64_pixel_iteration"] = v["instructions_per_launch"] / chunk_iterations
+            stored["valu"] = v
+            mem_sat = stored.get("traffic_GBs_with_this_runs_duration", dom["achieved_GBs"]) / HBM_PEAK_GBS
+            stored["nearer_saturated"] = "valu" if v["busy"] > mem_sat else "hbm"
+        if ctx.get("hbm_stream_measured") is not None:
+            stored["hbm_stream_measured"] = ctx["hbm_stream_measured"]
+    roofline["from_stored_profile"] = stored
+    roofline["step_wall_ms"] = step_wall_ms
 
     # ---- shipped thresholds (reference termination), same resident inputs ---------------------
     ref_term = None
@@ -448,10 +502,13 @@ def main():
         barrier()
         k2 = max(2, args.steps)
         wall2, lv2 = run_steps(eng, src, tgt, k2, use_dist, device, n_global)           # one enqueue at a time: event spans
+        steps_serial = step_wall_summary()
         barrier()
         wall2_serial = wall2
+        steps_pipelined = None
         if args.pipeline != "off":
             wall2, _ = run_steps(eng, src, tgt, k2, use_dist, device, n_global, pipelined=True)
+            steps_pipelined = step_wall_summary()
             barrier()
         if use_dist:
             tmax = torch.tensor([wall2, wall2_serial], dtype=torch.float64, device=device)
@@ -466,6 +523,8 @@ def main():
                 hist[f"level_{l}"] = {int(v): int(c) for v, c in zip(vals, counts)}
         ref_term = dict(value=n_global * k2 / wall2, unit="alignments/s", steps=k2,
                         pipelined=args.pipeline != "off", one_enqueue_at_a_time=n_global * k2 / wall2_serial,
+                        distinct_pairs=distinct,
+                        step_wall_ms=dict(one_enqueue_at_a_time=steps_serial, pipelined=steps_pipelined),
                         mean_iterations_per_level=[float(x) for x in it2.mean(axis=0)],
                         max_iterations_per_level=[int(x) for x in it2.max(axis=0)],
                         avg_launch_ms_per_level=[float(x) / k2 for x in lv2[:nl]],

@@ -236,6 +236,17 @@ int phovo_engine_set_slide_policy(phovo_engine *e, int policy);
  * three; poses agree to the parity bar between AUTO and OFF (other summation order on the smaller levels). */
 enum { PHOVO_FUSION_AUTO = 0, PHOVO_FUSION_OFF = -1, PHOVO_FUSION_SPLIT = -2 };
 int phovo_engine_set_level_fusion(phovo_engine *e, int mode);
+/* Long pairs last (the fused launch only, i.e. data-dependent termination).  With thresholds most pairs leave a level
+ * after 1-4 iterations and a few run to max_num_iterations (:383); which ones is not known before they have, and a batch
+ * whose pairs are simply taken in order ends with the long pairs that happened to be drawn last, each alone on its CU.
+ * iterations = K > 0: a pair that has not terminated a level after K iterations while the batch still holds pairs nobody
+ * has looked at is set aside (state vector and iteration count back to HBM) and continued -- from exactly there, by
+ * whichever workgroup is free -- once every pair has been looked at, so that the long pairs of a batch run side by side
+ * at its end instead of one after the other behind it.  Scheduling only: an iteration depends on nothing but the state
+ * vector, so states, iteration counts and reports are bit-identical for every K (tests/test_gpu_fused.py).
+ * 0: off.  Default PHOVO_PROBE_ITERATIONS_DEFAULT. */
+enum { PHOVO_PROBE_ITERATIONS_DEFAULT = 6 };
+int phovo_engine_set_probe_iterations(phovo_engine *e, int iterations);
 /* 1: a pair's result does not depend on how many other pairs are aligned with it -- every batch, whatever its size,
  * takes the SAME kernels with the same geometries (no latency geometry for <= 8 pairs, no automatic wide form for
  * <= 32 pairs), so a sequence cut into shards
@@ -325,7 +336,14 @@ int phovo_engine_results_device_ptr(phovo_engine *e, void **states);
  *       if (k > 0) phovo_engine_fetch(e, t[k - 1], n, states[k - 1], NULL);      // waits for enqueue k - 1 only
  *     }
  *     phovo_engine_fetch(e, t[steps - 1], n, states[steps - 1], NULL);
- * Results do not depend on what else is in flight (same kernels, same arithmetic per pair). */
+ * Results do not depend on what else is in flight (same kernels, same arithmetic per pair).
+ * A refused enqueue (bad argument, a level that cannot run) takes no ticket and evicts nothing; one that fails later (an
+ * allocation, a launch) leaves its slot empty, and every ticket-taking call refuses it.  An enqueue of zero pairs is an
+ * enqueue (ticket, nothing to fetch, no device buffer).
+ * Footprint: pair data (src, tgt, states, reports: 208 B per pair) and its pinned mirrors exist per slot; the large scratch
+ * -- owner maps of levels above ~39 k pixels (4 B per pixel and pair: 10 GB for 8192 pairs on 640x480 level 0), ballots,
+ * the wide form's workspace -- exists ONCE as long as the caller has one enqueue in flight at a time (it changes hands
+ * between the slots) and twice only while two enqueues really overlap. */
 #define PHOVO_ENQUEUE_DEPTH 2
 int phovo_engine_last_ticket(const phovo_engine *e);                       /* 0 before the first enqueue */
 int phovo_engine_wait(phovo_engine *e, int ticket);                        /* host wait for that enqueue alone */

@@ -19,7 +19,9 @@ def level_size(w, h, level):
 
 
 def resize_level(img, level):
-    """cv::resize by 2^-L from level 0 (INTER_LINEAR; 2x -> area fast path).  Even sizes only."""
+    """cv::resize by 2^-L from level 0 (INTER_LINEAR; 2x -> area fast path).  Sizes divisible by 2^L only: the twin does
+    not restate the clipped-border branches of phovo_oracle.c (tagged UNVERIFIED-vs-OpenCV there: recalled OpenCV behaviour
+    that nothing in this repository can check and that no BASELINE shape reaches), so those are pinned by nothing."""
     if level == 0:
         return img.copy()
     s = 1 << level
@@ -49,7 +51,8 @@ def scharr(img, scale):
 
 def gaussian_blur_twice(img, ksize):
     """cv::GaussianBlur(img, img, Size(k, k), 3) twice (...Analytic.h:146-147): separable, kernel
-    exp(-(i - (k-1)/2)^2 / (2*3^2)) normalised, BORDER_REFLECT_101 (scipy's "mirror")."""
+    exp(-(i - (k-1)/2)^2 / (2*3^2)) normalised, BORDER_REFLECT_101 (scipy's "mirror").  UNVERIFIED vs OpenCV like the C
+    oracle's (kernel, normalisation, summation order, border are recalled); no shipped analytic yml sets blurFilterSize > 0."""
     if ksize <= 1:
         return img.copy()
     from scipy.ndimage import correlate1d

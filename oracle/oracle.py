@@ -86,6 +86,10 @@ def lib():
             C.POINTER(Config), dp, C.POINTER(Level), dp, C.POINTER(C.c_int),
             C.POINTER(TraceEntry), C.c_int, dp, C.c_int, C.c_int]
         L.phovo_oracle_optimize_ext.restype = C.c_int
+        L.phovo_oracle_unverified_hits.argtypes = [C.c_int]
+        L.phovo_oracle_unverified_hits.restype = C.c_long
+        L.phovo_oracle_unverified_reset.argtypes = []
+        L.phovo_oracle_unverified_reset.restype = None
         L.phovo_oracle_warp_image.argtypes = [
             C.c_void_p, dp, C.c_int, C.c_int, dp, dp, C.c_int, C.c_void_p]
         _lib = L
@@ -181,6 +185,20 @@ def _intensity_pyramid(gray_u8, cfg):
                 img = lv                                   # the in-place blur of the aliased level 0
         pyr.append(lv)
     return pyr
+
+
+UNVERIFIED_BRANCHES = ("resize by 2: clipped block at an odd border", "resize by >= 4: tap clipped to the last row / column",
+                       "GaussianBlur")
+
+
+def unverified_hits(reset=False):
+    """How often the pyramid branches tagged UNVERIFIED-vs-OpenCV in phovo_oracle.c (restated from recalled OpenCV behaviour
+    and reached by no BASELINE shape) have run since the last reset: a tuple in the order of UNVERIFIED_BRANCHES."""
+    L = lib()
+    hits = tuple(int(L.phovo_oracle_unverified_hits(i)) for i in range(len(UNVERIFIED_BRANCHES)))
+    if reset:
+        L.phovo_oracle_unverified_reset()
+    return hits
 
 
 def build_source_pyramids(gray_u8, depth, cfg):

@@ -58,6 +58,24 @@ void phovo_oracle_eigen_pose(const double s[6], double rt[16])
 /* ------------------------------------------------------------------------- */
 /* Pyramid producers (OpenCV semantics; ...Analytic.h:115-189,466-491)        */
 /* ------------------------------------------------------------------------- */
+/* WHAT THIS ORACLE CANNOT VOUCH FOR.  OpenCV is not in /root/reference and not in the image: everything in this section
+ * is restated from recalled OpenCV 2.4 behaviour and pinned only against oracle/numpy_twin.py, never against OpenCV.
+ * The branches below that no BASELINE shape reaches are tagged UNVERIFIED-vs-OpenCV and counted when they execute
+ * (phovo_oracle_unverified_hits), so that tests/test_oracle_properties.py can assert that 640x480 and 1280x960 pyramids of
+ * every shipped yml stay out of them:
+ *   [0] resize, scale 2: the clipped 2x2 block at an odd border (sum / count in double; OpenCV's ResizeAreaFast tail is
+ *       recalled to go through the generic area path, possibly with float casts)
+ *   [1] resize, scale >= 4: a tap clipped to the last row / column (weights 1 / 0; how OpenCV builds its index and
+ *       coefficient tables at the border is recalled, not checked)
+ *   [2] GaussianBlur (any blurFilterSize > 0): kernel coefficients, their normalisation, the row / column summation
+ *       order and the border mode.  No shipped analytic yml sets blurFilterSize > 0.
+ * Not counted because every run takes them: the summation order of the scale-2 area mean, of the bilinear taps and of
+ * the Scharr row / column filters.  Those are restated too -- a different association changes the last bit of a plane,
+ * not the algorithm -- and that is why parity tests feed the SAME pyramids (the build's own) to both sides and a caller
+ * who needs OpenCV's own planes hands them over with phovo_engine_set_level_planes. */
+static long g_unverified[3];
+long phovo_oracle_unverified_hits(int which) { return (which >= 0 && which < 3) ? g_unverified[which] : -1; }
+void phovo_oracle_unverified_reset(void) { g_unverified[0] = g_unverified[1] = g_unverified[2] = 0; }
 void phovo_oracle_convert_intensity(const uint8_t *src, int n, double *dst)
 {
   const double a = 1. / 255;                 /* convertTo(..., 1./255)  :471 */
@@ -95,7 +113,8 @@ void phovo_oracle_resize_level(const double *src, int w, int h, int level, doubl
           const double a = src[(size_t)sy * w + sx], b = src[(size_t)sy * w + sx + 1];
           const double c = src[(size_t)(sy + 1) * w + sx], d = src[(size_t)(sy + 1) * w + sx + 1];
           dst[(size_t)dy * lw + dx] = (((a + b) + c) + d) * 0.25;
-        } else {                                  /* clipped block at an odd border */
+        } else {                                  /* clipped block at an odd border: UNVERIFIED-vs-OpenCV [0] */
+          g_unverified[0]++;
           double sum = 0; int count = 0;
           for (int yy = 0; yy < 2; yy++) {
             if (sy + yy >= h) break;
@@ -114,10 +133,10 @@ void phovo_oracle_resize_level(const double *src, int w, int h, int level, doubl
   const int half = s / 2 - 1;
   for (int dy = 0; dy < lh; dy++) {
     int sy = dy * s + half; double wy1 = 0.5;
-    if (sy >= h - 1) { sy = h - 1; wy1 = 0.0; }
+    if (sy >= h - 1) { sy = h - 1; wy1 = 0.0; g_unverified[1]++; }      /* UNVERIFIED-vs-OpenCV [1] */
     for (int dx = 0; dx < lw; dx++) {
       int sx = dx * s + half; double wx1 = 0.5;
-      if (sx >= w - 1) { sx = w - 1; wx1 = 0.0; }
+      if (sx >= w - 1) { sx = w - 1; wx1 = 0.0; g_unverified[1]++; }    /* UNVERIFIED-vs-OpenCV [1] */
       double top, bot;
       if (wx1 != 0.0) {
         top = src[(size_t)sy * w + sx] * 0.5 + src[(size_t)sy * w + sx + 1] * 0.5;
@@ -222,6 +241,7 @@ static void gaussian_blur_once(double *img, int w, int h, int ksize)
 void phovo_oracle_gaussian_blur_twice(double *img, int w, int h, int ksize)
 {
   if (ksize <= 0) return;                        /* if( blurFilterSize>0 )  :144 */
+  g_unverified[2]++;                             /* UNVERIFIED-vs-OpenCV [2]: the whole filter */
   gaussian_blur_once(img, w, h, ksize);
   gaussian_blur_once(img, w, h, ksize);
 }

@@ -127,6 +127,12 @@ void phovo_oracle_warp_image(const uint8_t *intensity, const double *depth,
                              int w, int h, const double rt[16], const double k[9],
                              int level, uint8_t *warped);
 
+/* How often the branches tagged UNVERIFIED-vs-OpenCV in phovo_oracle.c have executed since the last reset (process-wide,
+ * not thread-safe: the pyramid producers run on one thread in every test): 0 = scale-2 resize, clipped block at an odd
+ * border; 1 = scale >= 4 resize, tap clipped to the last row / column; 2 = GaussianBlur.  -1 for any other index. */
+long phovo_oracle_unverified_hits(int which);
+void phovo_oracle_unverified_reset(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "phovo_internal.hpp"
@@ -118,6 +119,7 @@ struct phovo_engine {
 
   int slide_policy = 0;                        // 0 automatic (where the owner map exceeds LDS), -1 never
   int fusion = PHOVO_FUSION_AUTO;              // consecutive levels in one launch (phovo_engine_set_level_fusion)
+  int probe_iterations = PHOVO_PROBE_ITERATIONS_DEFAULT;   // fused launch: long pairs are set aside after this many iterations of a level (0: off)
   int cu_count = 256;
   int wide_policy = 0;                         // 0 auto, 1 always (where possible), -1 never
   bool batch_invariant = false;                // every batch takes the same kernels and geometries (phovo_engine_set_batch_invariant)
@@ -620,6 +622,14 @@ int phovo_engine_set_level_fusion(phovo_engine *e, int mode)
   return PHOVO_OK;
 }
 
+int phovo_engine_set_probe_iterations(phovo_engine *e, int iterations)
+{
+  if (!e) return fail(PHOVO_E_INVALID_ARGUMENT, "set_probe_iterations: null engine");
+  if (iterations < 0) return fail(PHOVO_E_INVALID_ARGUMENT, "set_probe_iterations: iterations < 0");
+  e->probe_iterations = iterations;          // (read when an enqueue is issued: nothing in flight is affected)
+  return PHOVO_OK;
+}
+
 int phovo_engine_set_batch_invariant(phovo_engine *e, int on)
 {
   if (!e) return fail(PHOVO_E_INVALID_ARGUMENT, "set_batch_invariant: null");
@@ -963,25 +973,10 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
       return fail(PHOVO_E_INVALID_ARGUMENT, "align: frame index out of range");
   }
   PHOVO_HIP_CHECK(hipSetDevice(e->device));
-  // The slot this enqueue takes: the one used least recently.  Its previous enqueue (ticket - PHOVO_ENQUEUE_DEPTH) must
-  // have finished -- its pinned mirror and pair data are about to be rewritten -- but the enqueue before this one may
-  // still be running: it lives in the other slot, on the other stream.
-  const int ticket = ++e->ticket;
-  AlignSlot &s = e->slots[ticket % PHOVO_ENQUEUE_DEPTH];
-  PHOVO_HIP_CHECK(hipStreamSynchronize(s.stream));
-  s.ticket = ticket;
-  s.last_pairs = n_pairs;
-  s.have_timing = false;
-  s.launches.clear();
-  for (bool &b : s.level_launched) b = false;
-  if (n_pairs == 0) return PHOVO_OK;
-  // planes written on the engine's own stream so far (uploads return synchronised; plane setters too): nothing to order
-  int st = ensure_pairs(s, n_pairs);
-  if (st != PHOVO_OK) return st;
-
-  // every active level must be launchable before anything is enqueued
+  // Every active level must be launchable BEFORE the enqueue takes a ticket and a slot: a refused enqueue leaves the
+  // engine as it was -- in particular the results of the enqueue before the last stay fetchable.
   size_t owner_need = 0, wide_need = 0, mask_need = 0;
-  for (int l = 0; l < e->cfg.num_levels; l++) {
+  for (int l = 0; l < e->cfg.num_levels && n_pairs > 0; l++) {
     if (e->cfg.max_num_iterations[l] <= 0) continue;
     const LevelPool &lv = e->levels[l];
     if (!lv.stored) return fail(PHOVO_E_NOT_READY, "align: an active level is not resident");
@@ -1003,8 +998,49 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
       if (need > mask_need) mask_need = need;
     }
   }
+  // The slot this enqueue takes: the one used least recently.  Its previous enqueue (ticket - PHOVO_ENQUEUE_DEPTH) must
+  // have finished -- its pinned mirror and pair data are about to be rewritten -- but the enqueue before this one may
+  // still be running: it lives in the other slot, on the other stream.
+  const int ticket = e->ticket + 1;
+  AlignSlot &s = e->slots[ticket % PHOVO_ENQUEUE_DEPTH];
+  PHOVO_HIP_CHECK(hipStreamSynchronize(s.stream));
+  // From here on the slot's previous content is gone.  It holds NO enqueue until this one has been issued completely: a
+  // failure on the way (an allocation, a launch) leaves a slot that every ticket-taking entry point refuses, instead of one
+  // that hands out whatever an earlier enqueue left in its buffers.
+  s.ticket = 0;
+  s.last_pairs = n_pairs;
+  s.have_timing = false;
+  s.launches.clear();
+  for (bool &b : s.level_launched) b = false;
+  s.d_states = nullptr;
+  if (n_pairs == 0) {                    // nothing to run: a valid, empty enqueue (fetch of 0 pairs succeeds, no device buffer)
+    e->ticket = ticket;
+    s.ticket = ticket;
+    return PHOVO_OK;
+  }
+  // planes written on the engine's own stream so far (uploads return synchronised; plane setters too): nothing to order
+  int st = ensure_pairs(s, n_pairs);
+  if (st != PHOVO_OK) return st;
+
+  // Scratch in HBM (owner maps, ballots, the wide form's workspace) belongs to a slot, because two enqueues in flight must
+  // not share it -- but a caller that never has two in flight (align_pairs, the apps: one enqueue, one fetch) alternates
+  // between the slots and would keep TWO copies of buffers that reach gigabytes on level 0 (8192 pairs x 307 200 pixels:
+  // 10 GB of owner map).  So a slot that needs more than it has first looks at the OTHER slot: if that one is idle, its
+  // buffer changes hands (nothing of it is in use); only with two enqueues really in flight does a second buffer appear.
+  AlignSlot &other = e->slots[(ticket + 1) % PHOVO_ENQUEUE_DEPTH];
+  const bool other_idle = other.stream && hipStreamQuery(other.stream) == hipSuccess;
+  if (owner_need > s.owner_capacity && other_idle && other.owner_capacity >= owner_need) {
+    std::swap(s.d_owner, other.d_owner); std::swap(s.owner_capacity, other.owner_capacity); std::swap(s.owner_tagged, other.owner_tagged);
+  }
+  if (mask_need > s.mask_capacity && other_idle && other.mask_capacity >= mask_need) {
+    std::swap(s.d_mask, other.d_mask); std::swap(s.mask_capacity, other.mask_capacity);
+  }
+  if (wide_need > s.wide_ws_capacity && other_idle && other.wide_ws_capacity >= wide_need) {
+    std::swap(s.d_wide_ws, other.d_wide_ws); std::swap(s.wide_ws_capacity, other.wide_ws_capacity);
+  }
   if (owner_need > s.owner_capacity) {
-    if (s.d_owner) { PHOVO_HIP_CHECK(hipStreamSynchronize(s.stream)); (void)hipFree(s.d_owner); s.d_owner = nullptr; s.owner_capacity = 0; }
+    if (s.d_owner) { (void)hipFree(s.d_owner); s.d_owner = nullptr; s.owner_capacity = 0; }
+    if (other_idle && other.d_owner) { (void)hipFree(other.d_owner); other.d_owner = nullptr; other.owner_capacity = 0; }      // (too small for this batch: do not keep it beside the new one)
     PHOVO_HIP_CHECK(hipMalloc(&s.d_owner, sizeof(int) * owner_need));
     s.owner_capacity = owner_need;
     s.owner_tagged = false;
@@ -1014,11 +1050,13 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
 
   if (mask_need > s.mask_capacity) {
     if (s.d_mask) { (void)hipFree(s.d_mask); s.d_mask = nullptr; s.mask_capacity = 0; }
+    if (other_idle && other.d_mask) { (void)hipFree(other.d_mask); other.d_mask = nullptr; other.mask_capacity = 0; }
     PHOVO_HIP_CHECK(hipMalloc(&s.d_mask, sizeof(unsigned long long) * mask_need));
     s.mask_capacity = mask_need;
   }
   if (wide_need > s.wide_ws_capacity) {
-    if (s.d_wide_ws) { PHOVO_HIP_CHECK(hipStreamSynchronize(s.stream)); (void)hipFree(s.d_wide_ws); s.d_wide_ws = nullptr; s.wide_ws_capacity = 0; }
+    if (s.d_wide_ws) { (void)hipFree(s.d_wide_ws); s.d_wide_ws = nullptr; s.wide_ws_capacity = 0; }
+    if (other_idle && other.d_wide_ws) { (void)hipFree(other.d_wide_ws); other.d_wide_ws = nullptr; other.wide_ws_capacity = 0; }
     PHOVO_HIP_CHECK(hipMalloc(&s.d_wide_ws, wide_need));
     s.wide_ws_capacity = wide_need;
   }
@@ -1116,7 +1154,14 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
         for (int i = 0; i < n_run; i++) {
           f.lv[i] = level_args(run[i]);
           if (f.lv[i].n > f.n_max) f.n_max = f.lv[i].n;
+          // (the hand-over lists of these levels are otherwise unused: they belong to the sliding-window form; zeroed above)
+          f.defer_list[i] = s.d_handover + (size_t)run[i] * lay.handover_stride;
         }
+        // long pairs last: only worth it when the batch outnumbers the workgroups that can run at once
+        f.probe_iterations = n_pairs > persistent_grid(2) ? e->probe_iterations : 0;
+#ifdef PHOVO_TUNING
+        if (const char *k = std::getenv("PHOVO_PROBE_ITERATIONS")) f.probe_iterations = std::atoi(k);
+#endif
         PHOVO_HIP_CHECK(gn_launch_fused(f, e->ext.plane_storage, e->cu_count, s.stream));
         record(l, run[n_run - 1], PHOVO_LAUNCH_FUSED, 512, gn_fused_lds_bytes(f.n_max), persistent_grid(2));
         PHOVO_HIP_CHECK(hipEventRecord(s.ev_stop[l], s.stream));
@@ -1180,6 +1225,8 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
   }
   PHOVO_HIP_CHECK(hipEventRecord(s.ev_total_stop, s.stream));
   s.have_timing = true;
+  e->ticket = ticket;                  // issued completely: the enqueue exists
+  s.ticket = ticket;
   return PHOVO_OK;
 }
 

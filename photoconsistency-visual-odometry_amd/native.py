@@ -8,8 +8,12 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# PHOVO_HIP_LIBRARY selects a diagnostic build (e.g. the phase-stamp build of csrc/Makefile `stamps`).
-_SO = os.environ.get("PHOVO_HIP_LIBRARY") or os.path.join(_HERE, "libphovo_hip.so")
+# The product library, always -- unless a tools/ entry point has opted in to a diagnostic build (tools/_variant.py sets
+# PHOVO_TOOLS_LIBRARY_OPT_IN=tools before the package is imported and names the build in PHOVO_HIP_LIBRARY: csrc/Makefile
+# `variant`).  PHOVO_HIP_LIBRARY alone is ignored, so nothing in the environment can swap the library under tests, bench.py
+# or an application.
+_OVERRIDE = os.environ.get("PHOVO_HIP_LIBRARY") if os.environ.get("PHOVO_TOOLS_LIBRARY_OPT_IN") == "tools" else None
+_SO = _OVERRIDE or os.path.join(_HERE, "libphovo_hip.so")
 _CSRC = os.path.join(_HERE, "csrc")
 MAX_LEVELS = 16
 
@@ -64,6 +68,7 @@ class PairReport(C.Structure):
 
 
 FUSION_AUTO, FUSION_OFF, FUSION_SPLIT = 0, -1, -2
+PROBE_ITERATIONS_DEFAULT = 6
 LAUNCH_KINDS = ("persistent", "fused", "slide", "slide_fallback", "wide", "bilinear")
 
 
@@ -120,6 +125,7 @@ SYMBOLS = {
     "phovo_engine_set_wide_policy": (C.c_int, [_vp, C.c_int]),
     "phovo_engine_set_level_fusion": (C.c_int, [_vp, C.c_int]),
     "phovo_engine_set_batch_invariant": (C.c_int, [_vp, C.c_int]),
+    "phovo_engine_set_probe_iterations": (C.c_int, [_vp, C.c_int]),
     "phovo_engine_set_slide_policy": (C.c_int, [_vp, C.c_int]),
     "phovo_engine_level_uses_wide": (C.c_int, [_vp, C.c_int, C.c_int]),
     "phovo_host_register": (C.c_int, [_vp, C.c_size_t]),
@@ -175,7 +181,7 @@ def lib():
             build()
         L = C.CDLL(_SO)
         for name, (res, args) in SYMBOLS.items():
-            if os.environ.get("PHOVO_HIP_LIBRARY") and not hasattr(L, name):
+            if _OVERRIDE and not hasattr(L, name):
                 continue                     # a diagnostic / older build named explicitly (tools/ A-B runs): bind what it has
             fn = getattr(L, name)            # AttributeError if the ABI and the header diverge
             fn.restype = res

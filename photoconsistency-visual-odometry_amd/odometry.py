@@ -218,6 +218,11 @@ class AlignmentEngine:
         sizes gives bit-identical poses)."""
         check(self._lib.phovo_engine_set_batch_invariant(self._h, int(bool(on))), "phovo_engine_set_batch_invariant")
 
+    def set_probe_iterations(self, iterations):
+        """Fused launch: pairs still iterating after this many iterations of a level are set aside until every pair of the
+        batch has been looked at (scheduling only, results bit-identical); 0 = off."""
+        check(self._lib.phovo_engine_set_probe_iterations(self._h, int(iterations)), "phovo_engine_set_probe_iterations")
+
     def set_slide_policy(self, policy):
         """0 automatic (sliding-window kernel on levels whose owner map exceeds LDS), -1 exact kernel only."""
         check(self._lib.phovo_engine_set_slide_policy(self._h, int(policy)), "phovo_engine_set_slide_policy")

@@ -203,12 +203,14 @@ def make_pair(seed, width=640, height=480, holes=0.0, trans=0.03, rot=0.015, sce
     return dict(gray0=g0, depth0=d0, gray1=g1, depth1=d1, K=K, motion=m)
 
 
-def make_sequence(seed, n_frames, width=640, height=480, holes=0.0, trans=0.02, rot=0.01, scene="plane", invalid=0.2):
+def make_sequence(seed, n_frames, width=640, height=480, holes=0.0, trans=0.02, rot=0.01, scene="plane", invalid=0.2,
+                  workers=1):
     """A sequence of n_frames of one scene under cumulative small motions.
 
     Returns dict(gray [F,H,W] u8, depth [F,H,W] f64, K, poses [F,4,4] (T_t0),
     motions [F-1,4,4] where motions[t] = T_{t+1,0} . T_{t,0}^-1 is the ground truth
-    of pair (t, t+1)).  scene as in make_pair."""
+    of pair (t, t+1)).  scene as in make_pair.  workers > 1: the frames are rendered by that many threads (the poses are
+    chained first, every frame has its own seed: the result does not depend on `workers`)."""
     rs = np.random.RandomState((7919 * seed + 3) % (2 ** 32))
     layered = scene == "layered"
     if not layered and scene != "plane":
@@ -216,21 +218,28 @@ def make_sequence(seed, n_frames, width=640, height=480, holes=0.0, trans=0.02, 
     scene = LayeredScene(seed) if layered else Scene(seed)
     K = intrinsics(width, height)
     T = np.eye(4)
-    grays, depths, poses = [], [], []
+    poses = []
     for f in range(n_frames):
         if f > 0:
             T = eigen_pose(random_motion(rs, trans, rot)) @ T
-        if layered:
-            g, d = render_layered(scene, T, width, height, K, invalid, frame_seed=seed * 100003 + f)
-        else:
-            g, d = render(scene, T, width, height, K, holes, hole_seed=seed * 100003 + f)
-        grays.append(g)
-        depths.append(d)
         poses.append(T.copy())
+
+    def frame(f):
+        if layered:
+            return render_layered(scene, poses[f], width, height, K, invalid, frame_seed=seed * 100003 + f)
+        return render(scene, poses[f], width, height, K, holes, hole_seed=seed * 100003 + f)
+
+    if workers > 1 and n_frames > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=int(workers)) as pool:
+            frames = list(pool.map(frame, range(n_frames)))
+    else:
+        frames = [frame(f) for f in range(n_frames)]
     poses = np.stack(poses)
     motions = np.stack([poses[t + 1] @ np.linalg.inv(poses[t]) for t in range(n_frames - 1)]) \
         if n_frames > 1 else np.zeros((0, 4, 4))
-    return dict(gray=np.stack(grays), depth=np.stack(depths), K=K, poses=poses, motions=motions)
+    return dict(gray=np.stack([g for g, _ in frames]), depth=np.stack([d for _, d in frames]), K=K, poses=poses,
+                motions=motions)
 
 
 def half_pixel_problem(w=64, h=48, sign=1.0):

@@ -113,6 +113,31 @@ def test_visual_odometry_app_matches_oracle_pipeline(tmp_path):
     assert outs["rccl"] == outs["batch"]
 
 
+def test_visual_odometry_app_ends_with_an_error_when_a_shard_fails(tmp_path):
+    """--batch --gpus N [--rccl]: a shard that fails before the collective (injected: PHOVO_VO_INJECT_SHARD_FAILURE names the
+    shard) must end the run with its message and a non-zero status -- the shards vote before the all_gather
+    (apps/rccl/shard_vote.h), nobody waits in it for the rank that stays away.  One device here: one RCCL rank, and two
+    shards sharing the device without RCCL (RCCL itself refuses two ranks on one device, which is an error exit as well)."""
+    _write_tum(tmp_path, 4, K_VO)
+    exe = os.path.join(BIN, "PhotoconsistencyVisualOdometry")
+    for extra, env_extra, message in (
+            (["--batch", "--gpus", "1", "--rccl"], {"PHOVO_VO_INJECT_SHARD_FAILURE": "0"}, "failure injected"),
+            (["--batch", "--gpus", "2"], {"PHOVO_VO_INJECT_SHARD_FAILURE": "1", "PHOVO_VO_SHARE_DEVICES": "1"}, "failure injected"),
+            (["--batch", "--gpus", "2", "--rccl"], {"PHOVO_VO_SHARE_DEVICES": "1"}, "one rank per device")):
+        r = subprocess.run([exe, CFG5, str(tmp_path), str(tmp_path / "out" / "t.txt")] + extra, capture_output=True, text=True,
+                           timeout=120, env=dict(os.environ, **env_extra))
+        assert r.returncode != 0 and message in r.stderr, (extra, r.returncode, r.stderr)
+    # more shards than pairs (3 pairs, 5 shards sharing the device): the empty shards are ranks of nothing and the file is the batch's
+    outs = []
+    for extra in (["--batch"], ["--batch", "--gpus", "5"]):
+        out = tmp_path / "out" / f"t{len(outs)}.txt"
+        r = subprocess.run([exe, CFG5, str(tmp_path), str(out)] + extra, capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, PHOVO_VO_SHARE_DEVICES="1"))
+        assert r.returncode == 0, r.stderr
+        outs.append(_read_trajectory(out))
+    assert outs[0] == outs[1]
+
+
 def test_frame_alignment_app_matches_oracle(tmp_path):
     p = synthetic.make_pair(4, 640, 480, holes=0.01)
     for i in (0, 1):

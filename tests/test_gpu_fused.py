@@ -233,3 +233,102 @@ def test_fused_run_of_two_small_levels_at_another_image_size():
         assert se3.state_distance(s[0], es) < POSE_TOL, (mode, se3.state_distance(s[0], es))
         assert all(np.array_equal(s[0], s[k]) for k in range(300))
     assert np.array_equal(out[native.FUSION_AUTO][0], out[native.FUSION_SPLIT][0])
+
+
+def test_long_pairs_set_aside_and_continued_give_the_same_bits():
+    """phovo_engine_set_probe_iterations: in the fused launch a pair still iterating after K iterations of a level, while the
+    batch holds pairs nobody has looked at, is set aside and continued once the queue is empty -- by another workgroup, most
+    likely on another XCD.  Scheduling only: states, iteration counts, valid-pixel counts, gradient norms and flags are
+    bit-identical for K = 0 (off), 1 (nearly every pair goes through the lists, twice: once per level), 3 and the default,
+    including a pair that ends non-finite (its flag is raised before it is set aside or after, never lost) and non-zero
+    initial states; and they equal the oracle's."""
+    ncfg = native.read_config_file(os.path.join(CFG_DIR, "config_4_level_optimization_analytic.yml"))
+    nl = ncfg.num_levels
+    max_iter, min_grad = list(ncfg.max_num_iterations[:nl]), list(ncfg.min_gradient_norm[:nl])
+    ocfg = oracle.make_config(num_levels=nl, max_iter=max_iter, min_grad=min_grad)
+    probs = _problems()
+    # one more problem whose target is blank: zero gradients -> a singular 6x6 system on the first iteration -> non-finite
+    blank = dict(probs[0])
+    blank["gray1"] = np.zeros_like(probs[0]["gray1"])
+    probs.append(blank)
+    expect = [oracle.align_frames(ocfg, p["K"], p["gray0"], p["depth0"], p["gray1"]) for p in probs[:-1]]
+    order = np.random.RandomState(31).randint(0, len(probs), size=4000)
+    src, tgt = [2 * int(i) for i in order], [2 * int(i) + 1 for i in order]
+    out = {}
+    with odometry.AlignmentEngine() as eng:
+        eng.set_config(ncfg)
+        eng.set_intrinsic_matrix(probs[0]["K"])
+        _upload(eng, probs)
+        for k in (0, 1, 3, native.PROBE_ITERATIONS_DEFAULT):
+            eng.set_probe_iterations(k)
+            out[k] = eng.align_pairs(src, tgt, want_reports=True)
+            assert [r["kind"] for r in eng.last_launches()] == ["fused"]
+        with pytest.raises(native.PhovoError):
+            eng.set_probe_iterations(-1)
+    s0, r0 = out[0]
+    for k, (s, r) in out.items():
+        assert np.array_equal(s, s0, equal_nan=True), k
+        for a, b in zip(r, r0):
+            assert list(a.iterations[:nl]) == list(b.iterations[:nl]) and list(a.valid_pixels[:nl]) == list(b.valid_pixels[:nl]), k
+            assert a.flags == b.flags and (a.gradient_norm == b.gradient_norm or (a.gradient_norm != a.gradient_norm)), k
+    for pos, i in enumerate(order):
+        if int(i) == len(probs) - 1:
+            assert r0[pos].flags & native.PAIR_NONFINITE
+            continue
+        es, eits = expect[int(i)]
+        assert list(r0[pos].iterations[:nl]) == eits and r0[pos].flags == 0, pos
+    for i in range(len(probs) - 1):
+        pos = int(np.flatnonzero(order == i)[0])
+        assert se3.state_distance(s0[pos], expect[i][0]) < POSE_TOL, i
+
+
+def test_a_refused_enqueue_leaves_the_engine_as_it_was():
+    """phovo_engine_enqueue_align validates before it takes a ticket and a slot: an enqueue that is refused (a frame index out
+    of range; a level that cannot run: > 2 097 151 pixels with more pairs than the wide form takes) hands out no ticket,
+    evicts nothing -- the results of BOTH enqueues in flight stay fetchable under their tickets, bit for bit -- and
+    fetch_results keeps meaning the last enqueue that exists.  An empty enqueue is an enqueue: ticket, zero pairs, no device
+    buffer; fetching another count under its ticket is refused."""
+    ncfg = native.read_config_file(os.path.join(CFG_DIR, "config_4_level_optimization_analytic.yml"))
+    probs = _problems()[:3]
+    src, tgt = [0, 2, 4] * 50, [1, 3, 5] * 50
+    with odometry.AlignmentEngine() as eng:
+        eng.set_config(ncfg)
+        eng.set_intrinsic_matrix(probs[0]["K"])
+        _upload(eng, probs)
+        first = eng.align_pairs(src, tgt)
+        eng.enqueue_align(src[:100], tgt[:100])
+        t1 = eng.last_ticket()
+        eng.enqueue_align(src, tgt)
+        t2 = eng.last_ticket()
+        assert t2 == t1 + 1
+        for bad_src in ([0, 2, 99], [-1]):
+            with pytest.raises(native.PhovoError) as err:
+                eng.enqueue_align(bad_src, [1] * len(bad_src))
+            assert err.value.status == native.E_INVALID_ARGUMENT
+        assert eng.last_ticket() == t2                                   # no ticket was handed out
+        assert np.array_equal(eng.fetch(t1, 100), first[:100])           # nothing was evicted
+        assert np.array_equal(eng.fetch(t2, len(src)), first)
+        assert np.array_equal(eng.fetch_results(len(src)), first)
+        eng.enqueue_align([], [])
+        t3 = eng.last_ticket()
+        assert t3 == t2 + 1 and eng.fetch(t3, 0).shape == (0, 6) and eng.device_states(t3) is None
+        with pytest.raises(native.PhovoError) as err:
+            eng.fetch(t3, 5)
+        assert err.value.status == native.E_INVALID_ARGUMENT
+        assert np.array_equal(eng.fetch(t2, len(src)), first)            # the other slot is untouched
+    # a configuration whose only active level is too large for the persistent kernels, in a batch too large for the wide form
+    big = native.make_config(num_levels=1, max_iter=[2], min_grad=[0.0])
+    g = np.zeros((1200, 1800), dtype=np.uint8)
+    d = np.ones((1200, 1800))
+    with odometry.AlignmentEngine() as eng:
+        eng.set_config(big)
+        eng.set_intrinsic_matrix(synthetic.intrinsics(1800, 1200))
+        eng.reserve_frames(2, 1800, 1200)
+        eng.upload_frame(0, g, d)
+        eng.upload_frame(1, g, d)
+        ok = eng.align_pairs([0], [1])                                   # one pair: the wide form, no size limit
+        t = eng.last_ticket()
+        with pytest.raises(native.PhovoError) as err:
+            eng.enqueue_align([0] * 40, [1] * 40)
+        assert err.value.status == native.E_SHAPE
+        assert eng.last_ticket() == t and np.array_equal(eng.fetch(t, 1), ok, equal_nan=True)

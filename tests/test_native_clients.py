@@ -130,3 +130,16 @@ def test_png_codec_under_asan_ubsan(tmp_path):
                 assert r.returncode == 0, r.stderr
             else:
                 assert r.returncode == 1, (name, mode, r.returncode, r.stderr)
+
+
+def test_shards_vote_before_the_collective(tmp_path):
+    """apps/rccl/shard_vote.h, the vote the shard threads of PhotoconsistencyVisualOdometry --batch --gpus N --rccl take before
+    the all_gather: with a blocking barrier standing in for the collective, a failing shard must keep EVERY shard out of it
+    (nobody waits for a rank that never comes) and every thread must return -- the program ends, within the timeout."""
+    exe = tmp_path / "shard_vote_test"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-pthread", "-I", os.path.join(ROOT, "apps"),
+                           os.path.join(ROOT, "tests", "native", "shard_vote_test.cpp"), "-o", str(exe)])
+    for shards, failing, expect in ((8, -1, "entered=8 told_ok=8 failed=0"), (8, 3, "entered=0 told_ok=0 failed=1"),
+                                    (2, 0, "entered=0 told_ok=0 failed=1"), (1, -1, "entered=1 told_ok=1 failed=0")):
+        r = subprocess.run([str(exe), str(shards), str(failing)], capture_output=True, text=True, timeout=20)
+        assert r.returncode == 0 and r.stdout.strip() == expect, (shards, failing, r.stdout, r.stderr)

@@ -229,3 +229,41 @@ def test_two_instruction_round_of_the_device_is_c_round_exactly():
     assert checked > 400000
     bad = float(np.nextafter(0.5, 0.0))
     assert float(np.floor(np.float64(bad) + 0.5)) == 1.0 and exact_round(bad) == 0          # why p is not 0.5
+
+
+def test_no_baseline_shape_reaches_what_the_oracle_cannot_vouch_for():
+    """oracle/phovo_oracle.c restates OpenCV's resize / GaussianBlur from recalled behaviour; the branches nothing here can
+    check -- the clipped 2x2 block of an odd-sized scale-2 resize, a bilinear tap clipped to the last row / column, the
+    Gaussian blur -- are tagged UNVERIFIED-vs-OpenCV and count their executions.  Every shape BASELINE.json names (640x480
+    with each shipped analytic yml, 1280x960 with the 6-level file: every level of the file, active or not, source and target
+    pyramids) stays out of all three; the counters themselves work (an odd size, a 7th level of 480 rows and a blur hit one
+    each)."""
+    import glob
+    import os
+    from phovo_amd import native
+    cfg_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "config_files")
+    ymls = sorted(glob.glob(os.path.join(cfg_dir, "*analytic.yml")))
+    assert len(ymls) == 4
+    shapes = [(640, 480, y) for y in ymls] + [(1280, 960, os.path.join(cfg_dir, "config_6_level_optimization_analytic.yml"))]
+    oracle.unverified_hits(reset=True)
+    rs = np.random.RandomState(0)
+    for w, h, yml in shapes:
+        n = native.read_config_file(yml)
+        nl = n.num_levels
+        cfg = oracle.make_config(num_levels=nl, blur=list(n.blur_filter_size[:nl]),
+                                 grad_scale=list(n.image_gradients_scaling_factor[:nl]),
+                                 max_iter=list(n.max_num_iterations[:nl]), min_grad=list(n.min_gradient_norm[:nl]))
+        gray = rs.randint(0, 256, size=(h, w)).astype(np.uint8)
+        depth = rs.uniform(0.5, 4.0, size=(h, w))
+        oracle.build_source_pyramids(gray, depth, cfg)
+        oracle.build_target_pyramids(gray, cfg)
+        assert oracle.unverified_hits() == (0, 0, 0), (w, h, os.path.basename(yml), oracle.unverified_hits())
+    # ... and the tagged branches are real: shapes outside BASELINE do reach them
+    img = rs.uniform(size=(53, 75))
+    oracle.resize_level(img, 1)                                    # odd size, scale 2: the clipped block
+    assert oracle.unverified_hits(reset=True)[0] > 0
+    oracle.resize_level(rs.uniform(size=(480, 640)), 6)            # 480 / 64 = 7.5 -> 8 rows: the last one is a clipped tap
+    assert oracle.unverified_hits(reset=True)[1] > 0
+    cfg = oracle.make_config(num_levels=1, blur=[5], max_iter=[1], min_grad=[0.0])
+    oracle.build_target_pyramids(rs.randint(0, 256, size=(48, 64)).astype(np.uint8), cfg)
+    assert oracle.unverified_hits(reset=True) == (0, 0, 1)

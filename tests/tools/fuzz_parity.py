@@ -39,6 +39,7 @@ big = "big" in sys.argv[3:]
 strips = "strips" in sys.argv[3:]
 bad, worst, variants, fallbacks = 0, 0.0, {}, 0
 worst_ratio, worst_cond, ill = 0.0, 0.0, 0
+worst_ill, ill_only_by_scaling = 0.0, 0
 
 
 def worst_condition(trace):
@@ -138,12 +139,17 @@ for case in range(cases):
     its = list(reps[0].iterations[:nl])
     finite = np.all(np.isfinite(es))
     cond = worst_condition(otrace)
-    bar = 1e-9 * max(1.0, cond / 1e5)
+    # flat 1e-9 up to cond(J^T J) = 1e5, scaled with the condition number above, and NEVER looser than the specification's
+    # own 1e-5 (north_star); iteration counts must agree whatever the conditioning
+    bar = min(1e-5, 1e-9 * max(1.0, cond / 1e5))
     if finite:
         d = se3.state_distance(s[0], es)
         ok = its == eits and d < bar and all(np.array_equal(s[0], s[i]) for i in range(n_pairs))
         worst_ratio, worst_cond = max(worst_ratio, d / bar), max(worst_cond, cond)
         ill += int(cond > 1e5)
+        if cond > 1e5:
+            worst_ill = max(worst_ill, d)
+            ill_only_by_scaling += int(ok and d >= 1e-9)
     else:                                   # the oracle ran into NaN (no valid pixel / singular H): flagged, not hidden
         d = 0.0
         ok = bool(reps[0].flags & native.PAIR_NONFINITE) and not np.all(np.isfinite(s[0]))
@@ -156,7 +162,9 @@ for case in range(cases):
     if (case + 1) % 500 == 0:                 # a long sweep must not look hung to whoever is watching its output
         print(f"... {case + 1} cases so far, {bad} failures, worst {worst:.3e}", flush=True)
 print(f"{cases} cases, {bad} failures, worst pose distance {worst:.3e}")
-print(f"largest cond(J^T J) {worst_cond:.2e}; {ill} cases above 1e5 (bar scaled); worst distance / bar {worst_ratio:.3f}")
+print(f"largest cond(J^T J) {worst_cond:.2e}; {ill} cases above 1e5 (bar scaled, capped at 1e-5): worst absolute distance among them "
+      f"{worst_ill:.3e}, {ill_only_by_scaling} of them passed only because of the scaling (distance >= 1e-9); "
+      f"worst distance / bar {worst_ratio:.3f}")
 print(f"pairs finished by the exact kernel after leaving the sliding window: {fallbacks} cases")
 print("launch geometries exercised (threads, owner in LDS, source in LDS, wide form): ", variants)
 sys.exit(1 if bad else 0)

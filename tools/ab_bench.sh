@@ -11,8 +11,8 @@ SHAPES=${*:-shipped fixed layered cfg3 shipped2048}
 mkdir -p "$OUT"
 run() {   # name, library ("" = in-tree), bench arguments
   local name=$1 lib=$2; shift 2
-  if [ -n "$lib" ]; then export PHOVO_HIP_LIBRARY=$(realpath "$lib"); else unset PHOVO_HIP_LIBRARY; fi
-  timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-reference-termination "$@" > "$OUT/$name.json" 2> "$OUT/$name.err"
+  local prog="bench.py"; [ -n "$lib" ] && prog="tools/bench_with.py $(realpath "$lib")"      # library B only through the tools/ opt-in
+  timeout -k 10 300 python3 $prog --no-cpu-baseline --no-reference-termination "$@" > "$OUT/$name.json" 2> "$OUT/$name.err"
   python3 tools/benchsum.py "$OUT/$name.json" "$name" || tail -3 "$OUT/$name.err"
 }
 for rep in 1 2; do

@@ -131,6 +131,24 @@ def launch_table(bench, stats_csv, traffic, sq, path):
     print(json.dumps(out, indent=1))
 
 
+def build_stamp(src):
+    """Which build the counters belong to: the sha256 of the libphovo_hip.so the profiled command loaded (written on the GPU
+    box by tools/profile_round.sh) and the commit this tree stands at when the summary is made.  bench.py takes a stored
+    profile's traffic for its own `roofline.traffic` only when that sha256 is the loaded library's."""
+    import subprocess
+    stamp = {}
+    f = os.path.join(src, "library.sha256")
+    if os.path.exists(f):
+        stamp["library_sha256"] = open(f).read().split()[0]
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        stamp["commit"] = subprocess.check_output(["git", "-C", root, "rev-parse", "HEAD"], text=True).strip()
+        stamp["tree_dirty"] = bool(subprocess.check_output(["git", "-C", root, "status", "--porcelain", "--", "photoconsistency-visual-odometry_amd/csrc", "include"], text=True).strip())
+    except Exception:
+        pass
+    return stamp
+
+
 def main():
     src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
     pairs = int(sys.argv[sys.argv.index("--pairs") + 1]) if "--pairs" in sys.argv else 8192
@@ -154,6 +172,7 @@ def main():
         cal = json.load(open(ref))["calibration"]
         cal["taken_from"] = os.path.basename(ref)
     out = dict(tag=tag, calibration=cal, kernels=[])
+    out.update(build_stamp(src))
     fetch, nf = mean_by_kernel(counter_rows(os.path.join(src, "pmc_fetch")), skip_first=2)
     write, _ = mean_by_kernel(counter_rows(os.path.join(src, "pmc_write")), skip_first=2)
     for (k, g), v in sorted(fetch.items()):
@@ -175,7 +194,7 @@ def main():
     json.dump(out, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
     sq = sq_summary(counter_rows(os.path.join(src, "pmc_sq")), pairs)
     if sq:
-        json.dump(dict(tag=tag, kernels=sq), open(os.path.join(dst, f"{tag}_pmc_sq.json"), "w"), indent=1)
+        json.dump(dict(tag=tag, kernels=sq, **build_stamp(src)), open(os.path.join(dst, f"{tag}_pmc_sq.json"), "w"), indent=1)
         print(json.dumps(sq, indent=1))
     if "--bench" in sys.argv:        # per-launch table: bench.py's own launch rows joined with the trace and the counters
         launch_table(json.loads(open(sys.argv[sys.argv.index("--bench") + 1]).read().strip().splitlines()[-1]),

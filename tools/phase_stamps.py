@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Where one pair's iterations spend their time inside the level kernels (diagnostic build of the library):
-    make -C photoconsistency-visual-odometry_amd/csrc EXTRA=-DPHOVO_PHASE_STAMPS BUILD=/tmp/build_stamps OUT=$PWD/photoconsistency-visual-odometry_amd/libphovo_hip_stamps.so
-    PHOVO_HIP_LIBRARY=photoconsistency-visual-odometry_amd/libphovo_hip_stamps.so python3 tools/phase_stamps.py [pairs [shipped]]
+    python3 tools/phase_stamps.py [pairs [shipped]]        (builds csrc/build_stamps/libphovo_hip_stamps.so: `make stamps`)
 Workgroup 0 prints, for every pair it draws and four of its waves, the 10 ns ticks spent in pass 1, at the barrier behind it,
 in pass 2, in the butterfly, at the barrier in front of the solve and in / waiting for the solve (csrc/gn_kernels.hip,
 PHOVO_STAMP).  Fixed-iteration mode of the 4-level configuration: 50 iterations at 80x60, 20 at 160x120.  (The printing
@@ -11,6 +10,9 @@ a workgroup sees the same load.)"""
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _variant  # noqa: E402
+_variant.use("stamps")
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import phovo_amd  # noqa: F401,E402
 from phovo_amd import native, odometry, synthetic  # noqa: E402

@@ -10,8 +10,9 @@ OUT=$(realpath -m "$1")
 shift
 ROOT=$(pwd)
 mkdir -p "$OUT"
-BENCH="python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-reference-termination $*"
+BENCH="python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-reference-termination --distinct 32 $*"      # (a later --distinct among the extra arguments wins)
 echo "$BENCH" > "$OUT/command.txt"
+sha256sum "$ROOT/photoconsistency-visual-odometry_amd/libphovo_hip.so" > "$OUT/library.sha256"      # which build the counters belong to
 cd /tmp
 export TMPDIR=/tmp
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/stats.log" 2>&1
