@@ -568,21 +568,26 @@ def main():
         single = {}
         with odometry.CPhotoconsistencyOdometryAnalytic(local_rank) as po:
             po.SetIntrinsicMatrix(seq["K"])
-            for name, cfg_one in (("shipped_thresholds", cfg_ref), ("fixed_iterations", cfg_fixed)):
-                po.SetConfiguration(cfg_one)
-                po.SetSourceFrame(seq["gray"][0], seq["depth"][0])
-                po.SetTargetFrame(seq["gray"][1], seq["depth"][1])
-                dev_ms, wall_ms = [], []
-                for _ in range(20):
-                    po.SetInitialStateVector(np.zeros(6))
-                    t0 = time.perf_counter()
-                    po.Optimize()
-                    wall_ms.append((time.perf_counter() - t0) * 1e3)
-                    dev_ms.append(po.LastOptimizeMilliseconds())
-                single[name] = dict(device_ms=float(np.median(dev_ms)), host_wall_ms=float(np.median(wall_ms)),
-                                    iterations=[int(v) for v in po.GetReport().iterations[:nl]])
+            for forms in ("default", "latency_forms"):
+                po.SetLatencyForms(forms == "latency_forms")
+                for name, cfg_one in (("shipped_thresholds", cfg_ref), ("fixed_iterations", cfg_fixed)):
+                    po.SetConfiguration(cfg_one)
+                    po.SetSourceFrame(seq["gray"][0], seq["depth"][0])
+                    po.SetTargetFrame(seq["gray"][1], seq["depth"][1])
+                    dev_ms, wall_ms = [], []
+                    for _ in range(20):
+                        po.SetInitialStateVector(np.zeros(6))
+                        t0 = time.perf_counter()
+                        po.Optimize()
+                        wall_ms.append((time.perf_counter() - t0) * 1e3)
+                        dev_ms.append(po.LastOptimizeMilliseconds())
+                    single.setdefault(forms, {})[name] = dict(
+                        device_ms=float(np.median(dev_ms)), host_wall_ms=float(np.median(wall_ms)),
+                        iterations=[int(v) for v in po.GetReport().iterations[:nl]])
         single["note"] = (f"one {W}x{H} pair per Optimize() call (SetSourceFrame/SetTargetFrame outside the timer, as the "
-                          "reference's FrameAlignment app times it): latency-bound, one workgroup per level")
+                          "reference's FrameAlignment app times it): latency-bound.  default: the kernels and geometries a batch "
+                          "takes (one arithmetic per pair: bit-identical to the same pair in a batch); latency_forms: the opt-in "
+                          "forms that finish soonest for one pair (phovo_odometry_set_latency_forms; last bits may differ)")
 
     # ---- CPU baseline: the oracle, one thread, bounded sample of the same workload ------------
     cpu = parity = None

@@ -119,6 +119,9 @@ class CPhotoconsistencyOdometryAnalytic : public CPhotoconsistencyOdometry<TPixe
   // Not in the reference: narrow plane storage / Huber IRLS weights (phovo_extensions in phovo_hip.h).
   // ReadConfigurationFile() also picks them up from the two optional yml keys.
   void SetExtensions(const phovo_extensions &ext) { Check(phovo_odometry_set_extensions(m_Handle, &ext), "SetExtensions"); }
+  // Not in the reference: Optimize() may take the forms that finish soonest for one pair (last bits may then differ from the
+  // same pair aligned in a batch); default off.
+  void SetLatencyForms(bool on) { Check(phovo_odometry_set_latency_forms(m_Handle, on ? 1 : 0), "SetLatencyForms"); }
 
   // Not in the reference: what Optimize() did (iterations per level, last gradient norm, flags) and
   // its device time.

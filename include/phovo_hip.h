@@ -173,6 +173,9 @@ int phovo_odometry_destroy(phovo_odometry *o);                             /* dt
 int phovo_odometry_read_configuration_file(phovo_odometry *o, const char *path);   /* :581 */
 int phovo_odometry_set_config(phovo_odometry *o, const phovo_config *cfg);
 int phovo_odometry_set_extensions(phovo_odometry *o, const phovo_extensions *ext);   /* not in the reference */
+/* not in the reference: 1 = Optimize() may take the forms that finish soonest for ONE pair (phovo_engine_set_latency_forms:
+ * last bits may then differ from the same pair aligned in a batch); default 0 */
+int phovo_odometry_set_latency_forms(phovo_odometry *o, int on);
 int phovo_odometry_set_min_depth(phovo_odometry *o, double min_depth);     /* :448 */
 int phovo_odometry_set_max_depth(phovo_odometry *o, double max_depth);     /* :454 */
 int phovo_odometry_set_intrinsic_matrix(phovo_odometry *o, const double k[9]);     /* :460, row-major 3x3 */
@@ -216,9 +219,11 @@ int phovo_engine_set_build_all_levels(phovo_engine *e, int on);
 /* How a level is run.  The persistent form gives every pair ONE workgroup for all iterations of a level (the
  * throughput form).  The wide form cuts a pair into tiles of 1024 pixels, one workgroup each, with two launches
  * per iteration and a host look at the "done" words every 8 iterations (the latency form for a handful of pairs on
- * a large level; reference-exact configuration only).  policy: 0 = automatic (wide iff n_pairs <= 32 and the level
- * has >= 16384 pixels; never with phovo_engine_set_batch_invariant), 1 = wide wherever possible, -1 = never.  Same
- * iteration counts and poses within the parity bar either way (the forms sum in different orders). */
+ * a large level; reference-exact configuration only).  policy: 0 = automatic, 1 = wide wherever possible, -1 = never.
+ * Automatic: wide iff n_pairs <= 32 and the level's owner map does not fit LDS (more than ~39 k pixels: 320x240,
+ * 640x480 -- one workgroup would need hundreds of microseconds per iteration there); never with
+ * phovo_engine_set_batch_invariant.  Same iteration counts and poses within the parity bar either way (the forms sum in
+ * different orders). */
 int phovo_engine_set_wide_policy(phovo_engine *e, int policy);
 /* Levels whose owner map exceeds LDS (more than ~39 k pixels) run the sliding-window kernel (owner ring in LDS) followed
  * by the exact kernel (owner map in HBM) for the pairs whose warp left the window.  policy: 0 = automatic (that), -1 =
@@ -236,23 +241,21 @@ int phovo_engine_set_slide_policy(phovo_engine *e, int policy);
  * three; poses agree to the parity bar between AUTO and OFF (other summation order on the smaller levels). */
 enum { PHOVO_FUSION_AUTO = 0, PHOVO_FUSION_OFF = -1, PHOVO_FUSION_SPLIT = -2 };
 int phovo_engine_set_level_fusion(phovo_engine *e, int mode);
-/* Long pairs last (the fused launch only, i.e. data-dependent termination).  With thresholds most pairs leave a level
- * after 1-4 iterations and a few run to max_num_iterations (:383); which ones is not known before they have, and a batch
- * whose pairs are simply taken in order ends with the long pairs that happened to be drawn last, each alone on its CU.
- * iterations = K > 0: a pair that has not terminated a level after K iterations while the batch still holds pairs nobody
- * has looked at is set aside (state vector and iteration count back to HBM) and continued -- from exactly there, by
- * whichever workgroup is free -- once every pair has been looked at, so that the long pairs of a batch run side by side
- * at its end instead of one after the other behind it.  Scheduling only: an iteration depends on nothing but the state
- * vector, so states, iteration counts and reports are bit-identical for every K (tests/test_gpu_fused.py).
- * 0: off.  Default PHOVO_PROBE_ITERATIONS_DEFAULT. */
-enum { PHOVO_PROBE_ITERATIONS_DEFAULT = 6 };
-int phovo_engine_set_probe_iterations(phovo_engine *e, int iterations);
-/* 1: a pair's result does not depend on how many other pairs are aligned with it -- every batch, whatever its size,
- * takes the SAME kernels with the same geometries (no latency geometry for <= 8 pairs, no automatic wide form for
- * <= 32 pairs), so a sequence cut into shards
- * of any sizes gives bit-identical poses.  What the sequence drivers set (apps/PhotoconsistencyVisualOdometry --batch,
- * sequence.py, bench.py).  0 (default): a handful of pairs takes the forms that finish soonest (same iteration counts,
- * poses within the parity bar of the batch forms, last bits may differ). */
+/* One arithmetic per pair.  The reference has one (CPhotoconsistencyOdometryAnalytic.h:500-563), and so has this library
+ * wherever it costs little: on every level whose owner map fits LDS (up to ~39 k pixels -- every active level of the
+ * shipped 4- and 5-level files on 640x480) a pair runs the SAME kernel in the same geometry whether it is aligned alone
+ * through phovo_odometry_optimize or as one of thousands in a batch, so its state vector is the same bit for bit
+ * (PhotoconsistencyVisualOdometry: the pair-by-pair loop and --batch write the same file).  Two switches move that line:
+ *   phovo_engine_set_latency_forms(e, 1)   a handful of pairs (<= 8 / <= 32) may take the forms that finish soonest on
+ *       those levels too: 512-thread workgroups for levels of <= 9.5 k pixels, the wide form from 16 384 pixels (160x120:
+ *       12 instead of 27 us per iteration).  Same iteration counts, poses within the parity bar of the batch forms, last
+ *       bits may differ.  Default 0.
+ *   phovo_engine_set_batch_invariant(e, 1) also levels ABOVE ~39 k pixels take the batch forms for every batch size (no
+ *       automatic wide form), so that a sequence cut into shards of any sizes gives bit-identical poses on every
+ *       configuration.  What the sequence drivers set (apps/PhotoconsistencyVisualOdometry --batch, sequence.py,
+ *       bench.py).  Default 0: one pair on 640x480 level 0 takes 22 us per iteration in the wide form, 520 us in one
+ *       workgroup. */
+int phovo_engine_set_latency_forms(phovo_engine *e, int on);
 int phovo_engine_set_batch_invariant(phovo_engine *e, int on);
 /* 1 if `level` would run in the wide form for a batch of n_pairs under the current settings. */
 int phovo_engine_level_uses_wide(const phovo_engine *e, int level, int n_pairs);

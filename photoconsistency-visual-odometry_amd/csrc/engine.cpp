@@ -119,10 +119,10 @@ struct phovo_engine {
 
   int slide_policy = 0;                        // 0 automatic (where the owner map exceeds LDS), -1 never
   int fusion = PHOVO_FUSION_AUTO;              // consecutive levels in one launch (phovo_engine_set_level_fusion)
-  int probe_iterations = PHOVO_PROBE_ITERATIONS_DEFAULT;   // fused launch: long pairs are set aside after this many iterations of a level (0: off)
   int cu_count = 256;
   int wide_policy = 0;                         // 0 auto, 1 always (where possible), -1 never
   bool batch_invariant = false;                // every batch takes the same kernels and geometries (phovo_engine_set_batch_invariant)
+  bool latency_forms = false;                  // a handful of pairs may take the forms that finish soonest also where a level has a one-workgroup form with its owner map in LDS (phovo_engine_set_latency_forms)
 };
 
 namespace {
@@ -202,13 +202,21 @@ void level_dims(int w, int h, int level, int *lw, int *lh)
 
 // A handful of pairs on a large level: cut every pair into many workgroups (gn_wide_kernels.hip) instead of
 // giving it one.  Only the reference-exact configuration (fp64 planes, no extension) takes this form.
-bool use_wide_level(const phovo_engine *e, int n_pairs, int n_pixels)
+// The forms sum in different orders, so where a level has a one-workgroup form that is fast enough -- its owner map fits LDS:
+// up to ~39 k pixels, every active level of the shipped 4- and 5-level files on 640x480 -- that form runs whatever the batch
+// size and a pair has ONE arithmetic (the reference has one, ...Analytic.h:500-563: Optimize() through the class surface and
+// the same pair in a batch of thousands agree bit for bit); the caller may trade that for latency
+// (phovo_engine_set_latency_forms).  Larger levels would take hundreds of microseconds per iteration in one workgroup:
+// there a handful of pairs takes the wide form unless the caller pins the batch forms (phovo_engine_set_batch_invariant).
+bool use_wide_level(const phovo_engine *e, int n_pairs, const LevelPool &lv)
 {
   if (e->wide_policy < 0) return false;
   if (e->ext.plane_storage != PHOVO_STORAGE_F64 || e->ext.sampling != PHOVO_SAMPLING_NEAREST_SCATTER) return false;
   if (e->wide_policy > 0) return true;
   if (e->batch_invariant) return false;        // the automatic choice looks at the batch size
-  return n_pairs * 8 <= 256 && n_pixels >= 16384;
+  if (n_pairs * 8 > 256) return false;
+  if (lv.plan_ok && lv.plan.owner_in_lds) return e->latency_forms && lv.n >= 16384;
+  return true;
 }
 
 constexpr int HEAD_SETS = 2;
@@ -622,11 +630,10 @@ int phovo_engine_set_level_fusion(phovo_engine *e, int mode)
   return PHOVO_OK;
 }
 
-int phovo_engine_set_probe_iterations(phovo_engine *e, int iterations)
+int phovo_engine_set_latency_forms(phovo_engine *e, int on)
 {
-  if (!e) return fail(PHOVO_E_INVALID_ARGUMENT, "set_probe_iterations: null engine");
-  if (iterations < 0) return fail(PHOVO_E_INVALID_ARGUMENT, "set_probe_iterations: iterations < 0");
-  e->probe_iterations = iterations;          // (read when an enqueue is issued: nothing in flight is affected)
+  if (!e) return fail(PHOVO_E_INVALID_ARGUMENT, "set_latency_forms: null");
+  e->latency_forms = on != 0;
   return PHOVO_OK;
 }
 
@@ -640,7 +647,7 @@ int phovo_engine_set_batch_invariant(phovo_engine *e, int on)
 int phovo_engine_level_uses_wide(const phovo_engine *e, int level, int n_pairs)
 {
   if (!e || level < 0 || level >= e->cfg.num_levels || e->n_frames == 0) return 0;
-  return use_wide_level(e, n_pairs, e->levels[level].n) && !(e->ext.huber_delta[level] > 0.0) ? 1 : 0;
+  return use_wide_level(e, n_pairs, e->levels[level]) && !(e->ext.huber_delta[level] > 0.0) ? 1 : 0;
 }
 
 int phovo_engine_set_build_all_levels(phovo_engine *e, int on)
@@ -981,7 +988,7 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
     const LevelPool &lv = e->levels[l];
     if (!lv.stored) return fail(PHOVO_E_NOT_READY, "align: an active level is not resident");
     if (e->ext.sampling == PHOVO_SAMPLING_BILINEAR) continue;       // no owner map, no LDS limit
-    const bool wide = use_wide_level(e, n_pairs, lv.n) && !(e->ext.huber_delta[l] > 0.0);
+    const bool wide = use_wide_level(e, n_pairs, lv) && !(e->ext.huber_delta[l] > 0.0);
     if (wide) {
       const size_t ws = gn_wide_workspace_bytes(lv.n, n_pairs);
       if (ws > wide_need) wide_need = ws;
@@ -1114,13 +1121,13 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
     return a;
   };
   // a handful of pairs leaves most CUs empty: such a batch takes the geometry with the shorter iteration
-  const bool few_batch = !e->batch_invariant && n_pairs <= LATENCY_PAIRS;
+  const bool few_batch = e->latency_forms && !e->batch_invariant && n_pairs <= LATENCY_PAIRS;
   // Can level l be one of several levels of ONE launch (gn_fused_kernel)?  The persistent scatter kernel with its owner map
   // in half a CU's LDS; not the latency geometry of a small batch, not the wide form.
   auto fusable = [&](int l) {
     const LevelPool &lv = e->levels[l];
     if (e->fusion == PHOVO_FUSION_OFF || e->ext.sampling == PHOVO_SAMPLING_BILINEAR || few_batch) return false;
-    if (use_wide_level(e, n_pairs, lv.n) && !(e->ext.huber_delta[l] > 0.0)) return false;
+    if (use_wide_level(e, n_pairs, lv) && !(e->ext.huber_delta[l] > 0.0)) return false;
     return gn_level_fusable(lv.n);
   };
 
@@ -1154,14 +1161,7 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
         for (int i = 0; i < n_run; i++) {
           f.lv[i] = level_args(run[i]);
           if (f.lv[i].n > f.n_max) f.n_max = f.lv[i].n;
-          // (the hand-over lists of these levels are otherwise unused: they belong to the sliding-window form; zeroed above)
-          f.defer_list[i] = s.d_handover + (size_t)run[i] * lay.handover_stride;
         }
-        // long pairs last: only worth it when the batch outnumbers the workgroups that can run at once
-        f.probe_iterations = n_pairs > persistent_grid(2) ? e->probe_iterations : 0;
-#ifdef PHOVO_TUNING
-        if (const char *k = std::getenv("PHOVO_PROBE_ITERATIONS")) f.probe_iterations = std::atoi(k);
-#endif
         PHOVO_HIP_CHECK(gn_launch_fused(f, e->ext.plane_storage, e->cu_count, s.stream));
         record(l, run[n_run - 1], PHOVO_LAUNCH_FUSED, 512, gn_fused_lds_bytes(f.n_max), persistent_grid(2));
         PHOVO_HIP_CHECK(hipEventRecord(s.ev_stop[l], s.stream));
@@ -1184,7 +1184,7 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
     if (e->ext.sampling == PHOVO_SAMPLING_BILINEAR) {
       PHOVO_HIP_CHECK(gn_launch_level_bilinear(a, e->ext.plane_storage, e->ext.jacobian_corrected != 0, e->cu_count, s.stream));
       record(l, l, PHOVO_LAUNCH_BILINEAR, 256, 0, persistent_grid(gn_bilinear_wgs_per_cu()));
-    } else if (use_wide_level(e, n_pairs, lv.n) && !(e->ext.huber_delta[l] > 0.0)) {
+    } else if (use_wide_level(e, n_pairs, lv) && !(e->ext.huber_delta[l] > 0.0)) {
       if (s.owner_tagged) {            // the wide form starts from -1 everywhere and leaves it so
         PHOVO_HIP_CHECK(fill_i32(s.d_owner, s.owner_capacity, -1, s.stream));
         s.owner_tagged = false;
@@ -1453,6 +1453,12 @@ int phovo_odometry_set_extensions(phovo_odometry *o, const phovo_extensions *ext
   const int st = phovo_engine_set_extensions(o->engine, ext);
   if (st == PHOVO_OK && ext->plane_storage != before) o->have_source = o->have_target = o->optimized = false;
   return st;
+}
+
+int phovo_odometry_set_latency_forms(phovo_odometry *o, int on)
+{
+  if (!o) return fail(PHOVO_E_INVALID_ARGUMENT, "set_latency_forms: null");
+  return phovo_engine_set_latency_forms(o->engine, on);
 }
 
 int phovo_odometry_read_configuration_file(phovo_odometry *o, const char *path)

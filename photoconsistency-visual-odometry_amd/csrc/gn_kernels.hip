@@ -47,20 +47,13 @@ namespace {
 
 #ifdef PHOVO_TIMELINE
 // Diagnostic build only (tools/timeline.py): when a pair started and ended on the 100 MHz wall clock (low 31 bits) and in
-// which workgroup, left in the report slots of levels 15 / 14 / 13 / 12, which no configuration of the tool uses.
+// which workgroup, left in the report slots of levels 15 / 14, which no configuration of the tool uses.
 #define PHOVO_TIMELINE_BEGIN const int tl_begin = (int)(wall_clock64() & 0x7fffffffull);
 #define PHOVO_TIMELINE_END(rep) { (rep).valid_pixels[15] = tl_begin; (rep).valid_pixels[14] = (int)(wall_clock64() & 0x7fffffffull); (rep).iterations[15] = (int)blockIdx.x; }
-#define PHOVO_TIMELINE_MARK(rep, slot) { (rep).valid_pixels[slot] = (int)(wall_clock64() & 0x7fffffffull); }
 #else
 #define PHOVO_TIMELINE_BEGIN
 #define PHOVO_TIMELINE_END(rep)
-#define PHOVO_TIMELINE_MARK(rep, slot)
 #endif
-
-constexpr int NEVER_PAUSE = 0x7fffffff;
-// Values of s_ctl[CTL_DONE] behind an iteration: the level goes on, it has terminated (:383,388), or it has reached
-// `pause_at` iterations without terminating (gn_fused_kernel's probe of a pair: what happens next is the caller's decision).
-enum { LEVEL_RUNNING = 0, LEVEL_DONE = 1, LEVEL_PAUSED = 2 };
 
 // LDS blocks of a workgroup (offsets are multiples of 8; s_owner is sized for the largest level the workgroup will run).
 struct LevelLds {
@@ -82,14 +75,9 @@ struct LevelLds {
 // per wave), else in an LDS ballot array.  TI / TD: storage type of the intensity+gradient planes / of the depth plane
 // (double = reference-exact).  PARK (owner map in LDS, no SRC_LDS): whatever LDS the geometry leaves unused keeps the depth of
 // the image's leading A.depth_lds_chunks chunks from pass 1 to pass 2 (the block L.i0).
-// pause_at: the level also stops -- s_ctl[CTL_DONE] = LEVEL_PAUSED, nothing lost: state in L.state, owner map clean -- when
-// `iteration` reaches this count without the termination test having fired; a later call with state_in_lds (same workgroup) or
-// with the state stored back to A.states (any workgroup) continues it bit for bit, because an iteration depends on nothing
-// but the state vector.  coherent_state: A.states[pair] was written by another workgroup of THIS launch (agent-scope loads).
 template <int T, bool SRC_LDS, bool OWNER_LDS, bool MASK_REG, typename TI, typename TD, bool PARK = false>
 __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds &L, const int pair, const bool state_in_lds,
-                                           int &iteration, double &last_gnorm, int &last_valid,
-                                           const int pause_at = NEVER_PAUSE, const bool coherent_state = false)
+                                           int &iteration, double &last_gnorm, int &last_valid)
 {
   constexpr int NW = T / WAVE;
 #ifdef PHOVO_PHASE_STAMPS
@@ -136,11 +124,7 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
   if (wave == 0) {
     double st[6];
 #pragma unroll
-    for (int j = 0; j < 6; j++) {
-      if (state_in_lds) st[j] = s_state[j];
-      else if (coherent_state) st[j] = __hip_atomic_load(&A.states[(size_t)pair * 6 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else st[j] = A.states[(size_t)pair * 6 + j];
-    }
+    for (int j = 0; j < 6; j++) st[j] = state_in_lds ? s_state[j] : A.states[(size_t)pair * 6 + j];
     write_pose_constants(st[0], st[1], st[2], st[3], st[4], st[5], s_cst, lane);
     if (lane == 0) {
 #pragma unroll
@@ -593,13 +577,12 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
       if (it >= A.max_iter) done = true;                                                // :383
       else if (gnorm < A.min_grad_norm) done = true;                                    // :388
       if (!finite) done = true;     // the reference would keep iterating on NaN; the result is the same NaN
-      const bool paused = !done && it >= pause_at;       // (the continuation's prologue rebuilds the pose constants)
 #ifdef PHOVO_PHASE_STAMPS
       asm volatile("" :: "v"(gnorm));
       const unsigned long long solve_t2 = wall_clock64();
       solve_sum[2] += solve_t2 - solve_t1;         // update, norm, termination
 #endif
-      if (!done && !paused) write_pose_constants(st[0], st[1], st[2], st[3], st[4], st[5], s_cst, lane);   // wave-uniform branch
+      if (!done) write_pose_constants(st[0], st[1], st[2], st[3], st[4], st[5], s_cst, lane);   // wave-uniform branch
 #ifdef PHOVO_PHASE_STAMPS
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       solve_sum[3] += wall_clock64() - solve_t2;   // sincos and pose constants
@@ -607,7 +590,7 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
       if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < 6; i++) s_state[i] = st[i];
-        s_ctl[CTL_DONE] = done ? LEVEL_DONE : (paused ? LEVEL_PAUSED : LEVEL_RUNNING);
+        s_ctl[CTL_DONE] = done ? 1 : 0;
         if (!finite) s_ctl[CTL_FLAGS] |= (int)PHOVO_PAIR_NONFINITE;
         if (last_valid < 6) s_ctl[CTL_FLAGS] |= (int)PHOVO_PAIR_RANK_DEFICIENT;
       }
@@ -717,162 +700,51 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
 // pairs' work of any level, and the batch has ONE drain.  All levels take the geometry of the largest one (T threads,
 // owner map in LDS sized for F.n_max pixels, register masks): per level the arithmetic and its order are those of
 // gn_level_kernel<T, ...> with the same T, so the two paths are bit-identical (tests/test_gpu_fused.py).
-//
-// Long pairs last (F.probe_iterations = K > 0).  How long a pair will iterate is not known before it has -- most stop after
-// 1-4 iterations of a level, a few run to max_num_iterations, and nothing in the first iterations tells them apart -- so with
-// pairs simply drawn in order the batch ends with whichever long pairs were drawn last, each alone on its CU for hundreds of
-// microseconds while the rest of the chip idles.  A pair that has not terminated a level after K iterations while the queue
-// still holds pairs nobody has looked at is therefore SET ASIDE: state vector and iteration count go back to HBM, its index
-// onto the level's list, and the workgroup draws the next unseen pair.  When the queue is empty the long pairs are all known
-// and all waiting: workgroups take them from the lists (finest level first: the longest jobs) and continue each from exactly
-// where it stopped -- an iteration depends on nothing but the state vector, so the result is bit-identical to the pair run in
-// one go (tests/test_gpu_fused.py) -- and the chip drains over many long jobs started together instead of a few started late.
-// A pair that reaches K iterations when the queue is already empty just goes on.  Every list entry is consumed: whoever
-// appends one draws again afterwards and looks at the lists itself before it leaves.
-struct FusedTask {
-  int pair;       // n_pairs: nothing left
-  int resume;     // 0: a pair nobody has looked at; i + 1: a pair set aside at level lv[i], to be continued there
-};
-
-__device__ __forceinline__ bool queue_has_unseen_pairs(const GNFusedArgs &F)
-{
-  // (the queue of this workgroup's XCD: when that one is empty the others are about to be)
-  const int per = (F.n_pairs + F.n_queues - 1) / F.n_queues;
-  const int q = (int)(blockIdx.x & (unsigned)(F.n_queues - 1));
-  const int first = q * per;
-  const int size = first >= F.n_pairs ? 0 : (first + per > F.n_pairs ? F.n_pairs - first : per);
-  return __hip_atomic_load(F.work_counter + q * QUEUE_HEAD_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < size;
-}
-
-// Called by ONE thread.
-__device__ __forceinline__ FusedTask draw_task(const GNFusedArgs &F)
-{
-  FusedTask t;
-  t.pair = draw_pair(F.work_counter, F.n_queues, F.n_pairs);
-  t.resume = 0;
-  if (t.pair < F.n_pairs || F.probe_iterations <= 0) return t;
-  for (int i = F.n_levels - 1; i >= 0; i--) {               // finest level first: its iterations are the longest
-    int *const list = F.defer_list[i];
-    int *const reserved = list + F.n_pairs, *const taken = list + F.n_pairs + 1;
-    for (;;) {
-      const int h = __hip_atomic_load(taken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (h >= __hip_atomic_load(reserved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;      // nothing waiting here
-      if (atomicCAS(taken, h, h + 1) != h) continue;        // somebody else took slot h
-      // slot h has been reserved by a workgroup that writes it right after (set_aside): it cannot be long
-      int v;
-      while ((v = __hip_atomic_load(list + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) __builtin_amdgcn_s_sleep(2);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // the state and the report behind that entry (another XCD's L2)
-      t.pair = v - 1;
-      t.resume = i + 1;
-      return t;
-    }
-  }
-  return t;
-}
-
-// Called by ONE thread: `pair` stops at level lv[i] after `iteration` iterations; state in s_state, flags so far in `flags`.
-__device__ __forceinline__ void set_aside(const GNFusedArgs &F, int i, int pair, int iteration, const double *s_state, int flags)
-{
-  const GNLevelArgs &A = F.lv[i];
-#pragma unroll
-  for (int j = 0; j < 6; j++) A.states[(size_t)pair * 6 + j] = s_state[j];
-  A.reports[pair].iterations[A.level] = iteration;
-  if (flags) atomicOr(&A.reports[pair].flags, (uint32_t)flags);
-  PHOVO_TIMELINE_MARK(A.reports[pair], 13)
-  int *const list = F.defer_list[i];
-  const int slot = atomicAdd(list + F.n_pairs, 1);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // everything above is out of this XCD's L2 before the entry shows
-  __hip_atomic_store(list + slot, pair + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 template <int T, int WPS, typename TI, typename TD>
 __global__ __launch_bounds__(T, WPS) void gn_fused_kernel(const GNFusedArgs F)
 {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   const LevelLds L = carve_lds<T, false, true, true>(lds_raw, F.n_max, 0);
   int *const s_ctl = L.ctl;
-  int *const s_task = reinterpret_cast<int *>(L.state + 6);     // [0] FusedTask::resume, [1] "set aside" (the two spare doubles of the state block)
   const int tid = threadIdx.x;
   for (int k = tid; k < owner_lds_entries(F.n_max, T); k += T) L.owner[k] = -1;
-  if (tid == 0) {
-    const FusedTask t = draw_task(F);
-    s_ctl[CTL_PAIR] = t.pair;
-    s_task[0] = t.resume;
-  }
+  if (tid == 0) s_ctl[CTL_PAIR] = draw_pair(F.work_counter, F.n_queues, F.n_pairs);
   for (;;) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // see gn_level_kernel
     __syncthreads();
     const int pair = __builtin_amdgcn_readfirstlane(s_ctl[CTL_PAIR]);
     if (pair >= F.n_pairs) break;           // uniform: every wave of the workgroup leaves together
-    const int resume = __builtin_amdgcn_readfirstlane(s_task[0]);
 
     double last_gnorm = 0.0;
     PHOVO_TIMELINE_BEGIN
-    bool aside = false;
-    bool in_lds = false;                                    // the state is in L.state (a level of this pair has run here)
-    int li = resume ? resume - 1 : 0;
-    int iteration = 0;
-    if (resume) {
-      iteration = __builtin_amdgcn_readfirstlane(
-          __hip_atomic_load(&F.lv[li].reports[pair].iterations[F.lv[li].level], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      if (tid == 0) { PHOVO_TIMELINE_MARK(F.lv[li].reports[pair], 12) }
-    }
-    while (li < F.n_levels) {                               // coarse to fine  :502-503
+    for (int li = 0; li < F.n_levels; li++) {               // coarse to fine  :502-503
       const GNLevelArgs &A = F.lv[li];
-      int last_valid = 0;
+      int iteration = 0, last_valid = 0;
       // A level smaller than the largest leaves the tail of the owner map unused: the depth of its leading chunks is parked
       // there between the passes (level_body, PARK; gn_launch_fused sizes A.depth_lds_chunks), and the tail gets its -1 back
       // before the next level may need it as owner map (that level's prologue has the barriers).
       LevelLds Ll = L;
       int *const tail = L.owner + owner_lds_entries(A.n, T);
       Ll.i0 = reinterpret_cast<double *>(tail);
-      // a pair nobody has looked at is probed: up to probe_iterations iterations per level
-      const int pause_at = (!resume && iteration == 0 && F.probe_iterations > 0) ? F.probe_iterations : NEVER_PAUSE;
-      level_body<T, false, true, true, TI, TD, true>(A, Ll, pair, in_lds, iteration, last_gnorm, last_valid, pause_at,
-                                                     resume != 0);
-      in_lds = true;
+      level_body<T, false, true, true, TI, TD, true>(A, Ll, pair, li > 0, iteration, last_gnorm, last_valid);
       for (int k = tid; k < A.depth_lds_chunks * (int)(WAVE * sizeof(double) / sizeof(int)); k += T) tail[k] = -1;
-      // (workgroup-uniform, read behind level_body's closing barrier; saying so keeps `li` and everything indexed by it --
-      // the level's arguments, the buffer descriptors -- in scalar registers: an LDS word is divergent to the compiler)
-      if (__builtin_amdgcn_readfirstlane(s_ctl[CTL_DONE]) == LEVEL_PAUSED) {
-        if (tid == 0) {
-          const bool more = queue_has_unseen_pairs(F);
-          if (more) set_aside(F, li, pair, iteration, L.state, s_ctl[CTL_FLAGS]);
-#ifdef PHOVO_TIMELINE
-          if (more) A.reports[pair].valid_pixels[15] = tl_begin;
-#endif
-          s_task[1] = more ? 1 : 0;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (__builtin_amdgcn_readfirstlane(s_task[1])) { aside = true; break; }
-        continue;                                           // the queue is empty: nobody is waiting for this workgroup, go on
-      }
       if (tid == 0 && A.reports) {
         A.reports[pair].iterations[A.level] = iteration;
         A.reports[pair].valid_pixels[A.level] = last_valid;
       }
-      iteration = 0;
-      li++;
     }
 
     if (tid == 0) {
-      if (!aside) {
-        const GNLevelArgs &A = F.lv[0];
+      const GNLevelArgs &A = F.lv[0];
 #pragma unroll
-        for (int j = 0; j < 6; j++) A.states[(size_t)pair * 6 + j] = L.state[j];
-        if (A.reports) {
-          A.reports[pair].gradient_norm = last_gnorm;
-          const uint32_t new_flags = (uint32_t)s_ctl[CTL_FLAGS];
-          if (new_flags) atomicOr(&A.reports[pair].flags, new_flags);
-#ifdef PHOVO_TIMELINE
-          if (resume) { PHOVO_TIMELINE_MARK(A.reports[pair], 14) } else { PHOVO_TIMELINE_END(A.reports[pair]) }
-#endif
-        }
+      for (int j = 0; j < 6; j++) A.states[(size_t)pair * 6 + j] = L.state[j];
+      if (A.reports) {
+        A.reports[pair].gradient_norm = last_gnorm;
+        const uint32_t new_flags = (uint32_t)s_ctl[CTL_FLAGS];
+        if (new_flags) atomicOr(&A.reports[pair].flags, new_flags);
+        PHOVO_TIMELINE_END(A.reports[pair])
       }
-      const FusedTask t = draw_task(F);
-      s_ctl[CTL_PAIR] = t.pair;
-      s_task[0] = t.resume;
+      s_ctl[CTL_PAIR] = draw_pair(F.work_counter, F.n_queues, F.n_pairs);
     }
   }   // next pair
 }

@@ -63,13 +63,6 @@ struct GNFusedArgs {
   int n_pairs;
   int n_queues;
   int *work_counter;
-  // Long pairs last (gn_fused_kernel): with probe_iterations > 0 a pair that has not terminated a level after that many
-  // iterations, while the queue still holds pairs nobody has looked at, is set aside -- state and iteration count stored, its
-  // index appended to the level's list -- and continued, bit for bit, by whichever workgroup finds the queue empty.
-  // defer_list[i] (level lv[i]): [n_pairs + 2] ints, zeroed before the launch: entries pair + 1 (0 = not written yet) at
-  // [0, n_pairs), slots reserved at [n_pairs], slots taken at [n_pairs + 1].
-  int probe_iterations;
-  int *defer_list[GN_MAX_FUSED_LEVELS];
 };
 
 constexpr int QUEUES_PER_LEVEL = 8;      // one per XCD

@@ -68,7 +68,6 @@ class PairReport(C.Structure):
 
 
 FUSION_AUTO, FUSION_OFF, FUSION_SPLIT = 0, -1, -2
-PROBE_ITERATIONS_DEFAULT = 6
 LAUNCH_KINDS = ("persistent", "fused", "slide", "slide_fallback", "wide", "bilinear")
 
 
@@ -102,6 +101,7 @@ SYMBOLS = {
     "phovo_odometry_read_configuration_file": (C.c_int, [_vp, C.c_char_p]),
     "phovo_odometry_set_config": (C.c_int, [_vp, C.POINTER(Config)]),
     "phovo_odometry_set_extensions": (C.c_int, [_vp, C.POINTER(Extensions)]),
+    "phovo_odometry_set_latency_forms": (C.c_int, [_vp, C.c_int]),
     "phovo_odometry_set_min_depth": (C.c_int, [_vp, C.c_double]),
     "phovo_odometry_set_max_depth": (C.c_int, [_vp, C.c_double]),
     "phovo_odometry_set_intrinsic_matrix": (C.c_int, [_vp, _dp]),
@@ -125,7 +125,7 @@ SYMBOLS = {
     "phovo_engine_set_wide_policy": (C.c_int, [_vp, C.c_int]),
     "phovo_engine_set_level_fusion": (C.c_int, [_vp, C.c_int]),
     "phovo_engine_set_batch_invariant": (C.c_int, [_vp, C.c_int]),
-    "phovo_engine_set_probe_iterations": (C.c_int, [_vp, C.c_int]),
+    "phovo_engine_set_latency_forms": (C.c_int, [_vp, C.c_int]),
     "phovo_engine_set_slide_policy": (C.c_int, [_vp, C.c_int]),
     "phovo_engine_level_uses_wide": (C.c_int, [_vp, C.c_int, C.c_int]),
     "phovo_host_register": (C.c_int, [_vp, C.c_size_t]),

@@ -83,6 +83,11 @@ class CPhotoconsistencyOdometryAnalytic:
         """Not in the reference: plane storage / Huber weights (native.make_extensions)."""
         check(self._lib.phovo_odometry_set_extensions(self._h, C.byref(ext)), "SetExtensions")
 
+    def SetLatencyForms(self, on=True):
+        """Not in the reference: Optimize() may take the forms that finish soonest for one pair (last bits may then differ
+        from the same pair aligned in a batch); default off."""
+        check(self._lib.phovo_odometry_set_latency_forms(self._h, 1 if on else 0), "SetLatencyForms")
+
     def SetMinDepth(self, minD):
         check(self._lib.phovo_odometry_set_min_depth(self._h, float(minD)), "SetMinDepth")
 
@@ -218,10 +223,10 @@ class AlignmentEngine:
         sizes gives bit-identical poses)."""
         check(self._lib.phovo_engine_set_batch_invariant(self._h, int(bool(on))), "phovo_engine_set_batch_invariant")
 
-    def set_probe_iterations(self, iterations):
-        """Fused launch: pairs still iterating after this many iterations of a level are set aside until every pair of the
-        batch has been looked at (scheduling only, results bit-identical); 0 = off."""
-        check(self._lib.phovo_engine_set_probe_iterations(self._h, int(iterations)), "phovo_engine_set_probe_iterations")
+    def set_latency_forms(self, on=True):
+        """A handful of pairs may take the forms that finish soonest also on levels of <= ~39 k pixels (last bits may then
+        differ from the batch forms); default off: one arithmetic per pair on those levels."""
+        check(self._lib.phovo_engine_set_latency_forms(self._h, 1 if on else 0), "phovo_engine_set_latency_forms")
 
     def set_slide_policy(self, policy):
         """0 automatic (sliding-window kernel on levels whose owner map exceeds LDS), -1 exact kernel only."""

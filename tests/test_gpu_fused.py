@@ -136,9 +136,10 @@ def test_fused_launch_with_extensions_and_initial_states():
 
 def test_small_batches_and_thresholds_of_zero_take_one_launch_per_level():
     """Fusion is for data-dependent termination in a throughput batch: with min_gradient_norm = 0 (every pair runs
-    max_num_iterations; the mode bench.py times) the levels stay separate launches, each in its own best geometry, and so do
-    the latency forms of a batch of <= 8 pairs; with phovo_engine_set_batch_invariant even one pair takes the fused launch
-    (a pair's bits then do not depend on its batch)."""
+    max_num_iterations; the mode bench.py times) the levels stay separate launches, each in its own best geometry.  One pair
+    takes the fused launch like a batch does (a pair's bits do not depend on its batch on levels with the owner map in LDS)
+    unless the caller asks for the latency forms (phovo_engine_set_latency_forms), which phovo_engine_set_batch_invariant
+    overrides."""
     p = synthetic.make_pair(5, 640, 480, holes=0.01)
     thr = native.make_config(num_levels=4, max_iter=[0, 0, 6, 9], min_grad=[0.0, 0.0, 200.0, 200.0])
     fixed = native.make_config(num_levels=4, max_iter=[0, 0, 6, 9], min_grad=[0.0] * 4)
@@ -148,10 +149,13 @@ def test_small_batches_and_thresholds_of_zero_take_one_launch_per_level():
         _upload(eng, [p])
         eng.align_pairs([0] * 64, [1] * 64)
         assert [r["kind"] for r in eng.last_launches()] == ["fused"]
+        inv_one = eng.align_pairs([0], [1])
+        assert [r["kind"] for r in eng.last_launches()] == ["fused"]
+        eng.set_latency_forms(True)
         one = eng.align_pairs([0], [1])
         assert "fused" not in [r["kind"] for r in eng.last_launches()]
         eng.set_batch_invariant(True)
-        inv_one = eng.align_pairs([0], [1])
+        assert np.array_equal(eng.align_pairs([0], [1]), inv_one)
         assert [r["kind"] for r in eng.last_launches()] == ["fused"]
         inv_many = eng.align_pairs([0] * 700, [1] * 700)
         assert np.array_equal(inv_many, np.tile(inv_one, (700, 1)))
@@ -233,53 +237,6 @@ def test_fused_run_of_two_small_levels_at_another_image_size():
         assert se3.state_distance(s[0], es) < POSE_TOL, (mode, se3.state_distance(s[0], es))
         assert all(np.array_equal(s[0], s[k]) for k in range(300))
     assert np.array_equal(out[native.FUSION_AUTO][0], out[native.FUSION_SPLIT][0])
-
-
-def test_long_pairs_set_aside_and_continued_give_the_same_bits():
-    """phovo_engine_set_probe_iterations: in the fused launch a pair still iterating after K iterations of a level, while the
-    batch holds pairs nobody has looked at, is set aside and continued once the queue is empty -- by another workgroup, most
-    likely on another XCD.  Scheduling only: states, iteration counts, valid-pixel counts, gradient norms and flags are
-    bit-identical for K = 0 (off), 1 (nearly every pair goes through the lists, twice: once per level), 3 and the default,
-    including a pair that ends non-finite (its flag is raised before it is set aside or after, never lost) and non-zero
-    initial states; and they equal the oracle's."""
-    ncfg = native.read_config_file(os.path.join(CFG_DIR, "config_4_level_optimization_analytic.yml"))
-    nl = ncfg.num_levels
-    max_iter, min_grad = list(ncfg.max_num_iterations[:nl]), list(ncfg.min_gradient_norm[:nl])
-    ocfg = oracle.make_config(num_levels=nl, max_iter=max_iter, min_grad=min_grad)
-    probs = _problems()
-    # one more problem whose target is blank: zero gradients -> a singular 6x6 system on the first iteration -> non-finite
-    blank = dict(probs[0])
-    blank["gray1"] = np.zeros_like(probs[0]["gray1"])
-    probs.append(blank)
-    expect = [oracle.align_frames(ocfg, p["K"], p["gray0"], p["depth0"], p["gray1"]) for p in probs[:-1]]
-    order = np.random.RandomState(31).randint(0, len(probs), size=4000)
-    src, tgt = [2 * int(i) for i in order], [2 * int(i) + 1 for i in order]
-    out = {}
-    with odometry.AlignmentEngine() as eng:
-        eng.set_config(ncfg)
-        eng.set_intrinsic_matrix(probs[0]["K"])
-        _upload(eng, probs)
-        for k in (0, 1, 3, native.PROBE_ITERATIONS_DEFAULT):
-            eng.set_probe_iterations(k)
-            out[k] = eng.align_pairs(src, tgt, want_reports=True)
-            assert [r["kind"] for r in eng.last_launches()] == ["fused"]
-        with pytest.raises(native.PhovoError):
-            eng.set_probe_iterations(-1)
-    s0, r0 = out[0]
-    for k, (s, r) in out.items():
-        assert np.array_equal(s, s0, equal_nan=True), k
-        for a, b in zip(r, r0):
-            assert list(a.iterations[:nl]) == list(b.iterations[:nl]) and list(a.valid_pixels[:nl]) == list(b.valid_pixels[:nl]), k
-            assert a.flags == b.flags and (a.gradient_norm == b.gradient_norm or (a.gradient_norm != a.gradient_norm)), k
-    for pos, i in enumerate(order):
-        if int(i) == len(probs) - 1:
-            assert r0[pos].flags & native.PAIR_NONFINITE
-            continue
-        es, eits = expect[int(i)]
-        assert list(r0[pos].iterations[:nl]) == eits and r0[pos].flags == 0, pos
-    for i in range(len(probs) - 1):
-        pos = int(np.flatnonzero(order == i)[0])
-        assert se3.state_distance(s0[pos], expect[i][0]) < POSE_TOL, i
 
 
 def test_a_refused_enqueue_leaves_the_engine_as_it_was():

@@ -692,6 +692,9 @@ def test_every_kernel_variant_matches_oracle(size, expect):
         eng.upload_frame(0, p["gray0"], p["depth0"], roles=native.ROLE_SOURCE)
         eng.upload_frame(1, p["gray1"], None, roles=native.ROLE_TARGET)
         s, reps = eng.align_pairs([0] * 9, [1] * 9, want_reports=True)      # 9 pairs: the throughput geometry above
+        s_one = eng.align_pairs([0], [1])                                   # one pair, default: the SAME geometry, the same bits
+        assert np.array_equal(s_one[0], s[0])
+        eng.set_latency_forms(True)
         s1, reps1 = eng.align_pairs([0], [1], want_reports=True)            # a handful: the latency geometry (512 threads
     assert list(reps[0].iterations[:1]) == eits                             # where the throughput one has 4 x 256)
     assert se3.state_distance(s[0], es) < POSE_TOL
@@ -729,6 +732,11 @@ def test_wide_form_equals_persistent_form_and_oracle(size, levels, max_iter, min
         sw, rw = eng.align_pairs(src, tgt, want_reports=True)
         sw2 = eng.align_pairs(src, tgt)                                   # owner map clean again, deterministic
         eng.set_wide_policy(0)
+        # automatic: only where one workgroup per pair would be slow (owner map beyond LDS, > ~39 k pixels); with the latency
+        # forms asked for, from 16 384 pixels on
+        auto = [eng.level_uses_wide(l, 3) for l in range(levels)]
+        assert auto == [not eng.level_launch_info(l)["owner_in_lds"] for l in range(levels)]
+        eng.set_latency_forms(True)
         auto = [eng.level_uses_wide(l, 3) for l in range(levels)]
         assert auto == [eng.level_size(l)[0] * eng.level_size(l)[1] >= 16384 for l in range(levels)]
         assert not eng.level_uses_wide(0, 64)                              # many pairs: persistent form

@@ -96,6 +96,11 @@ def test_layered_scenes_640x480_match_oracle_on_every_form(yml, fixed):
         src = [2 * i for i in range(6)]
         tgt = [2 * i + 1 for i in range(6)]
         big = eng.align_pairs(src * 10, tgt * 10, want_reports=True)
+        # default: every level of these files has its owner map in LDS, so a pair has one arithmetic whatever its batch
+        assert not eng.level_uses_wide(2, 6)
+        same = eng.align_pairs(src, tgt)
+        assert np.array_equal(same, big[0][:6])
+        eng.set_latency_forms(True)                                 # ... unless the caller asks for the forms that finish soonest
         few = eng.align_pairs(src, tgt, want_reports=True)
         assert eng.level_uses_wide(2, 6) and not eng.level_uses_wide(2, 60)
         one = [eng.align_pairs([2 * i], [2 * i + 1], want_reports=True) for i in range(6)]
@@ -213,8 +218,10 @@ def test_batch_invariant_mode_gives_every_shard_size_the_same_bits():
     """101 frames = 100 pairs of one sequence with the VisualOdometry app's configuration (5 levels, shipped thresholds):
     aligned in ONE call, in 8 shards of 12-13 pairs (the 8-GPU node on a short sequence: fewer than 32 pairs per shard is
     where the automatic wide form used to step in), in shards of 5 and 7 pairs (<= 8: the latency geometry) and one pair
-    at a time.  With phovo_engine_set_batch_invariant every cut gives bit-identical states and identical reports;
-    without it the small shards take the latency forms -- same iteration counts, poses inside the parity bar."""
+    at a time.  Every cut gives bit-identical states and identical reports -- with phovo_engine_set_batch_invariant on any
+    configuration, and by default on this one, whose active levels all keep their owner map in LDS; with
+    phovo_engine_set_latency_forms the small shards take the latency forms -- same iteration counts, poses inside the parity
+    bar."""
     seq = synthetic.make_sequence(seed=77, n_frames=26, width=640, height=480, holes=0.01)
     order = [(f % 50) if (f % 50) < 26 else 50 - (f % 50) for f in range(101)]      # 0..25..0..25..: 101 frames from 26 renders
     ncfg = native.read_config_file(os.path.join(CFG_DIR, "config_5_level_optimization_analytic.yml"))
@@ -249,6 +256,10 @@ def test_batch_invariant_mode_gives_every_shard_size_the_same_bits():
                 assert list(a.valid_pixels[:nl]) == list(b.valid_pixels[:nl]) and a.gradient_norm == b.gradient_norm
         assert not eng.level_uses_wide(2, 12)
         eng.set_batch_invariant(False)
+        assert not eng.level_uses_wide(2, 12)                       # 160x120: owner map in LDS, one form for every batch size
+        got, _ = run(eng, cuts_of([5, 7] * 8 + [4]))
+        assert np.array_equal(got, whole)
+        eng.set_latency_forms(True)
         assert eng.level_uses_wide(2, 12)
         loose, rl = run(eng, cuts_of([5, 7] * 8 + [4]))
     worst = max(se3.state_distance(a, b) for a, b in zip(loose, whole))

@@ -48,14 +48,6 @@ def test_work_loop_head_is_the_barrier(kernels):
     branches or narrows the exec mask may come first (register spill moves and waits may)."""
     for name, body in kernels.items():
         heads = [i for i, l in enumerate(body) if "This Loop Header: Depth=1" in l]
-        if "gn_fused_kernel" in name:
-            # The fused kernel's draw (draw_task: queue, then the lists of pairs set aside) has loops of its own and is
-            # inlined once in front of the work loop: thread 0's code only, so no barrier may sit in it; the LAST outermost
-            # loop is the work queue.
-            assert 1 <= len(heads) <= 2, f"{name}: outermost loops: {len(heads)}"
-            for a, b in zip(heads[:-1], heads[1:]):
-                assert not any(l.strip() == "s_barrier" for l in body[a:b]), f"{name}: a barrier inside the first draw"
-            heads = heads[-1:]
         assert len(heads) == 1, f"{name}: expected exactly one outermost loop (the work queue), found {len(heads)}"
         if "gn_level_kernelILi64E" in name:
             # one wave per workgroup: the compiler drops every workgroup barrier (a wave is in step with itself and its LDS
@@ -192,9 +184,7 @@ def test_two_draws_from_the_queue(kernels):
         # block)
         if "gn_level_kernel_slide" in name:
             want = 2 * 1 + 1
-        elif "gn_fused_kernel" in name:
-            want = 2 * 1 + 1         # + the slot reservation of a pair that is set aside (set_aside; taking one is a compare-and-swap)
-        elif "gn_level_kernel_bilinear" in name:
+        elif "gn_level_kernel_bilinear" in name or "gn_fused_kernel" in name:
             want = 2 * 1
         else:
             want = 2 * 2

@@ -128,6 +128,8 @@ for case in range(cases):
             es, eits, otrace = oracle.optimize(ocfg, K, *planes, init_state=init, huber_delta=huber, bilinear=bilinear,
                                                corrected=corrected, want_trace=True)
         n_pairs = int(rs.choice([40, 300] if big else [1, 3, 40]))          # 40 > 32: never the wide form
+        if n_pairs <= 8 and rs.rand() < 0.5:
+            eng.set_latency_forms(True)         # half of the small batches: the forms that finish soonest (off by default)
         inits = None if init is None else np.tile(init, (n_pairs, 1))
         s, reps = eng.align_pairs([0] * n_pairs, [1] * n_pairs, init_states=inits, want_reports=True)
         for l in range(nl):

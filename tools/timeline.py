@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """When every pair of ONE enqueue started and ended (diagnostic build with per-pair wall-clock stamps, `make timeline`):
-    python3 tools/timeline.py [--pairs 8192] [--distinct 1024] [--probe K ...] [--yml config_4_level_optimization_analytic.yml]
-For each K (phovo_engine_set_probe_iterations; 0 = pairs simply taken in order) prints the enqueue's device time, the
-makespan seen by the stamps, when the last unseen pair was drawn, how many workgroups are busy over time (deciles of the
-makespan) and the longest pairs with their start times -- i.e. what the end of a batch with data-dependent termination looks
-like.  The stamps sit in report slots of levels 12-15, which the 4- and 5-level files do not use."""
+    python3 tools/timeline.py [--pairs 8192] [--distinct 1024] [--yml config_4_level_optimization_analytic.yml]
+Prints the enqueue's device time, the makespan seen by the stamps, when the last pair was drawn, how many workgroups are busy
+over time (deciles of the makespan) and the pairs that end last with their start times -- i.e. what the end of a batch with
+data-dependent termination looks like (profiles/r05_runs/).  The stamps sit in report slots of levels 14 and 15, which the
+4- and 5-level files do not use."""
 import argparse
 import os
 import sys
@@ -21,7 +21,6 @@ from phovo_amd import native, odometry, synthetic  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--pairs", type=int, default=8192)
 ap.add_argument("--distinct", type=int, default=1024)
-ap.add_argument("--probe", type=int, nargs="*", default=[0, 6])
 ap.add_argument("--yml", default="config_4_level_optimization_analytic.yml")
 ap.add_argument("--scene", default="plane")
 args = ap.parse_args()
@@ -42,8 +41,7 @@ with odometry.AlignmentEngine() as eng:
         src += [base + t for t in range(args.distinct)]
         tgt += [base + t + 1 for t in range(args.distinct)]
     src, tgt = np.array(src[:args.pairs], dtype=np.int32), np.array(tgt[:args.pairs], dtype=np.int32)
-    for k in args.probe:
-        eng.set_probe_iterations(k)
+    for k in (0,):
         for _ in range(3):
             eng.align_pairs(src, tgt)
         ms = []
@@ -56,14 +54,13 @@ with odometry.AlignmentEngine() as eng:
         TICK = 1e-2                                   # microseconds per tick of the 100 MHz wall clock
         begin = np.array([r.valid_pixels[15] for r in rep], dtype=np.int64)
         end = np.array([r.valid_pixels[14] for r in rep], dtype=np.int64)
-        aside = np.array([r.valid_pixels[13] for r in rep], dtype=np.int64)
-        back = np.array([r.valid_pixels[12] for r in rep], dtype=np.int64)
+        aside = back = np.zeros(len(rep), dtype=np.int64)
         its = np.array([list(r.iterations[:nl]) for r in rep])
         t0 = begin.min()
         b, e = (begin - t0) * TICK, (end - t0) * TICK                       # (a wrap of the 31-bit stamp inside one enqueue: every 21 s)
         span = e.max()
         was_aside = aside != 0
-        print(f"\n== probe_iterations {k}: launches {[(l['kind'], l['levels'], l['workgroups']) for l in launches]}")
+        print(f"\n== launches {[(l['kind'], l['levels'], l['workgroups']) for l in launches]}")
         print(f"device time of the enqueue (HIP events) {np.median(ms):.3f} ms [{min(ms):.3f} .. {max(ms):.3f}]; "
               f"first start to last end {span / 1e3:.3f} ms; last unseen pair drawn at {b.max() / 1e3:.3f} ms; "
               f"{int(was_aside.sum())} pairs set aside")
@@ -80,7 +77,7 @@ with odometry.AlignmentEngine() as eng:
                 busy += (grid >= b[i]) & (grid < e[i])
         dec = [int(busy[int(q * 200 / 10)]) for q in range(10)] + [int(busy[199])]
         print("busy workgroups at 0,10,...,90,99.5 % of the span:", dec)
-        idle_tail = float(np.trapz(np.maximum(busy.max() - busy, 0), grid) / busy.max())
+        idle_tail = float(np.trapezoid(np.maximum(busy.max() - busy, 0), grid) / busy.max())
         print(f"workgroup-time idle inside the span: {idle_tail / 1e3:.3f} ms-equivalents of the full grid "
               f"({100 * idle_tail / span:.1f} % of the span)")
         order = np.argsort(-(e))[:8]
