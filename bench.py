@@ -71,9 +71,6 @@ def parse():
                     help="plane storage (f64 = reference-exact; arithmetic is fp64 in every mode)")
     ap.add_argument("--huber", type=float, default=0.0, help="Huber delta on every level (0 = off)")
     ap.add_argument("--bilinear", action="store_true", help="bilinear forward-additive sampling + corrected Jacobian")
-    ap.add_argument("--no-level0-compaction", action="store_true",
-                    help="diagnostic (A/B): level 0 keeps fp64 intensities instead of the frame's bytes (phovo_engine_set_level0_compaction; "
-                         "only levels above ~39 k pixels are affected, i.e. --workload cfg1)")
     ap.add_argument("--max-iterations", default=None,
                     help="diagnostic, never the default: comma list overriding the yml's max_num_iterations, level 0 first "
                          "(e.g. 0,0,1,1 = every plane streamed exactly once: the HBM-only rate of the level kernels)")
@@ -382,8 +379,6 @@ def main():
 
     eng = odometry.AlignmentEngine(local_rank)
     eng.set_batch_invariant(True)      # the same kernels whatever --pairs is (no latency forms for small batches)
-    if args.no_level0_compaction:
-        eng.set_level0_compaction(False)
     storage_code = {"f64": native.STORAGE_F64, "f32": native.STORAGE_F32, "f16": native.STORAGE_F16}[args.storage]
     # bytes per pixel of the five planes a pixel-iteration reads (I0, D0, I1, GX1, GY1) in this storage
     plane_bytes = {"f64": 40.0, "f32": 20.0, "f16": 12.0}[args.storage]

@@ -212,16 +212,6 @@ int phovo_engine_set_extensions(phovo_engine *e, const phovo_extensions *ext);
 int phovo_engine_get_extensions(const phovo_engine *e, phovo_extensions *ext);
 int phovo_engine_set_intrinsic_matrix(phovo_engine *e, const double k[9]);
 int phovo_engine_set_depth_range(phovo_engine *e, double min_depth, double max_depth);
-/* Level 0 of a reference-exact pool (fp64 planes, no extension, no level-0 blur) whose owner map does not fit LDS -- more
- * than ~39 k pixels: 640x480 level 0, i.e. config_only_level_0_analytic.yml -- keeps its INTENSITY plane as the frame's own
- * bytes: what convertTo(., CV_64F, 1./255) makes of them (...Analytic.h:471,484) is double(k) * (1./255), and the kernels
- * rebuild exactly that on load, so every result is bit-identical to the fp64 plane's while two of the five planes a
- * pixel-iteration reads (I0, I1) shrink from 8 bytes to 1 -- those launches stream from HBM and are bound by it.
- * phovo_engine_get_level_planes returns the fp64 values; phovo_engine_set_level_planes accepts an intensity plane for such a
- * level only if it is a converted 8-bit image (every value double(k) * (1./255): what Set*Frame and OpenCV's own level 0
- * are) and refuses anything else with PHOVO_E_UNSUPPORTED.  on = 0 stores fp64 intensities everywhere (arbitrary planes
- * accepted).  Default 1.  Changing it drops the frame pool (call it before phovo_engine_reserve_frames). */
-int phovo_engine_set_level0_compaction(phovo_engine *e, int on);
 /* 0 (default): only levels with max_num_iterations > 0 are built and kept in HBM (the others are
  * never read by Optimize()).  1: every level, as the reference does (:474-475,487-490). */
 int phovo_engine_set_build_all_levels(phovo_engine *e, int on);

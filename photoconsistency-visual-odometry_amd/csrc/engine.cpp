@@ -43,9 +43,6 @@ struct LevelPool {
   unsigned char *planes = nullptr;   // frame f at planes + f*frame_bytes, plane p of it at + plane_off[p]
   size_t frame_bytes = 0;
   size_t plane_off[PLANES_PER_FRAME] = {0, 0, 0, 0};
-  int elem[PLANES_PER_FRAME] = {ELEM_F64, ELEM_F64, ELEM_F64, ELEM_F64};      // stored element type of each plane (phovo_internal.hpp)
-  bool packed = true;                  // [4][n] doubles: what the pyramid producers write directly
-  bool intensity_u8 = false;           // level 0 of a reference-exact pool that streams from HBM: the intensity plane is the frame's bytes
   GNLaunchPlan plan{};
   bool plan_ok = false;
   GNLaunchPlan plan_few{};             // geometry for a handful of pairs (LATENCY_PAIRS or fewer)
@@ -125,8 +122,6 @@ struct phovo_engine {
   int cu_count = 256;
   int wide_policy = 0;                         // 0 auto, 1 always (where possible), -1 never
   bool batch_invariant = false;                // every batch takes the same kernels and geometries (phovo_engine_set_batch_invariant)
-  bool compact_level0 = true;                  // phovo_engine_set_level0_compaction
-  int *d_flag = nullptr;                       // one int: "a plane handed over is not representable in the level's element type"
   bool latency_forms = false;                  // a handful of pairs may take the forms that finish soonest also where a level has a one-workgroup form with its owner map in LDS (phovo_engine_set_latency_forms)
 };
 
@@ -145,8 +140,7 @@ void free_pool(phovo_engine *e)
   if (e->d_blur_kernel) (void)hipFree(e->d_blur_kernel);
   if (e->d_scratch) (void)hipFree(e->d_scratch);
   if (e->d_blur0) (void)hipFree(e->d_blur0);
-  if (e->d_flag) (void)hipFree(e->d_flag);
-  e->d_scratch = nullptr; e->d_blur0 = nullptr; e->d_flag = nullptr;
+  e->d_scratch = nullptr; e->d_blur0 = nullptr;
   e->d_gray = nullptr; e->d_depth = nullptr; e->d_depth16 = nullptr; e->d_tmp = nullptr;
   e->d_blur_kernel = nullptr;
   e->stage_frames = 0; e->stage_has_f64 = e->stage_has_u16 = false;
@@ -301,6 +295,7 @@ int build_pyramids(phovo_engine *e, int first_frame, int count, int roles, Depth
   const uint8_t *s_gray = e->d_gray + px * (size_t)stage_offset;
   const double *s_depth = e->d_depth ? e->d_depth + px * (size_t)stage_offset : nullptr;
   const uint16_t *s_depth16 = e->d_depth16 ? e->d_depth16 + px * (size_t)stage_offset : nullptr;
+  const int storage = e->ext.plane_storage;
   // blurFilterSize[0] > 0: the converted level-0 image, blurred twice, is the image every other level is resized from
   // (whether or not level 0 itself is resident)
   const double *blurred0 = nullptr;
@@ -319,7 +314,9 @@ int build_pyramids(phovo_engine *e, int first_frame, int count, int roles, Depth
     // fp64 storage: the producers write straight into the pool.  Narrow storage: they write fp64 planes into
     // the scratch chunk (same [frame][4][n] layout) and a convert pass rounds them into the pool once.
     const size_t fstride = (size_t)PLANES_PER_FRAME * (size_t)lv.n;
-    double *base = lv.packed ? reinterpret_cast<double *>(lv.planes + (size_t)first_frame * lv.frame_bytes) : e->d_scratch;
+    double *base = storage == PHOVO_STORAGE_F64
+                       ? reinterpret_cast<double *>(lv.planes + (size_t)first_frame * lv.frame_bytes)
+                       : e->d_scratch;
     // BuildPyramid(intensity, applyBlur = true)  :474,487
     const int ks = e->cfg.blur_filter_size[l];
     const double *kern = ks > 0 ? e->d_blur_kernel + (size_t)l * e->blur_kernel_stride : nullptr;
@@ -351,14 +348,14 @@ int build_pyramids(phovo_engine *e, int first_frame, int count, int roles, Depth
       PHOVO_HIP_CHECK(pyr_scharr(base, fstride, (size_t)PLANE_I * lv.n, (size_t)PLANE_GX * lv.n,
                                  (size_t)PLANE_GY * lv.n, count, lv.w, lv.h,
                                  e->cfg.image_gradients_scaling_factor[l], e->stream));
-    if (!lv.packed) {
+    if (storage != PHOVO_STORAGE_F64) {
       unsigned char *dst = lv.planes + (size_t)first_frame * lv.frame_bytes;
       const bool want[PLANES_PER_FRAME] = {true, (roles & PHOVO_ROLE_SOURCE) != 0, (roles & PHOVO_ROLE_TARGET) != 0,
                                            (roles & PHOVO_ROLE_TARGET) != 0};
       for (int p = 0; p < PLANES_PER_FRAME; p++) {
         if (!want[p]) continue;
         PHOVO_HIP_CHECK(pyr_store_plane(base + (size_t)p * lv.n, fstride, count, lv.n, dst + lv.plane_off[p],
-                                        lv.frame_bytes, lv.elem[p], e->stream));
+                                        lv.frame_bytes, storage, p == PLANE_D, e->stream));
       }
     }
   }
@@ -568,9 +565,7 @@ int phovo_engine_set_extensions(phovo_engine *e, const phovo_extensions *ext)
                                      "(the scatter path is kept reference-exact)");
   for (int l = 0; l < PHOVO_MAX_LEVELS; l++)
     if (!(ext->huber_delta[l] == ext->huber_delta[l])) return fail(PHOVO_E_INVALID_ARGUMENT, "set_extensions: huber_delta is NaN");
-  bool bytes_in_pool = false;                            // a level that keeps byte intensities exists only under the scatter sampling
-  for (const LevelPool &lv : e->levels) bytes_in_pool = bytes_in_pool || (lv.stored && lv.intensity_u8);
-  if (ext->plane_storage != e->ext.plane_storage || (ext->sampling != e->ext.sampling && bytes_in_pool)) {      // the pool layout changes
+  if (ext->plane_storage != e->ext.plane_storage) {      // the pool layout changes
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
     (void)quiesce(e);
@@ -632,19 +627,6 @@ int phovo_engine_set_level_fusion(phovo_engine *e, int mode)
   if (mode != PHOVO_FUSION_AUTO && mode != PHOVO_FUSION_OFF && mode != PHOVO_FUSION_SPLIT)
     return fail(PHOVO_E_INVALID_ARGUMENT, "set_level_fusion: unknown mode");
   e->fusion = mode;
-  return PHOVO_OK;
-}
-
-int phovo_engine_set_level0_compaction(phovo_engine *e, int on)
-{
-  if (!e) return fail(PHOVO_E_INVALID_ARGUMENT, "set_level0_compaction: null");
-  if ((on != 0) != e->compact_level0) {          // the pool layout changes
-    (void)hipSetDevice(e->device);
-    (void)hipStreamSynchronize(e->stream);
-    (void)quiesce(e);
-    free_pool(e);
-  }
-  e->compact_level0 = on != 0;
   return PHOVO_OK;
 }
 
@@ -729,7 +711,6 @@ int phovo_engine_reserve_frames(phovo_engine *e, int n_frames, int width, int he
   free_pool(e);
   size_t max_n = 0;
   int max_ks = 0;
-  bool any_unpacked = false;
   for (int l = 0; l < e->cfg.num_levels; l++) {
     LevelPool &lv = e->levels[l];
     level_dims(width, height, l, &lv.w, &lv.h);
@@ -740,24 +721,15 @@ int phovo_engine_reserve_frames(phovo_engine *e, int n_frames, int width, int he
     lv.plan_ok = gn_plan_level(lv.n, &lv.plan, 0, fp64_planes);
     lv.plan_few_ok = gn_plan_level(lv.n, &lv.plan_few, 1, fp64_planes);
     {   // byte layout of one frame at this level: planes I, D, GX, GY.  fp64: packed [4][n] doubles, which is
-        // what the producer kernels write directly; anything else: every plane starts 16-byte aligned.
-      // Level 0 of a reference-exact pool keeps its INTENSITY plane as the frame's own bytes where the level streams from
-      // HBM (owner map beyond LDS: the sliding-window / exact / wide forms): convertTo's double(k) * (1./255) is rebuilt on
-      // load, exactly, and two of the five plane reads of a pixel-iteration shrink from 8 bytes to 1.  Not with a level-0
-      // blur (the plane is then a filtered image), not with the extensions.
-      lv.intensity_u8 = l == 0 && e->compact_level0 && fp64_planes && e->ext.sampling == PHOVO_SAMPLING_NEAREST_SCATTER &&
-                        e->cfg.blur_filter_size[0] <= 0 && !(lv.plan_ok && lv.plan.owner_in_lds);
-      for (int p = 0; p < PLANES_PER_FRAME; p++) lv.elem[p] = storage_elem(e->ext.plane_storage, p);
-      if (lv.intensity_u8) lv.elem[PLANE_I] = ELEM_U8_UNIT;
-      lv.packed = fp64_planes && !lv.intensity_u8;
+        // what the producer kernels write directly; narrow storages: every plane starts 16-byte aligned.
+      const bool packed = e->ext.plane_storage == PHOVO_STORAGE_F64;
       size_t off = 0;
       for (int p = 0; p < PLANES_PER_FRAME; p++) {
         lv.plane_off[p] = off;
-        const size_t bytes = elem_size(lv.elem[p]) * (size_t)lv.n;
-        off += lv.packed ? bytes : ((bytes + 15) & ~(size_t)15);
+        const size_t bytes = storage_elem_size(e->ext.plane_storage, p == PLANE_D) * (size_t)lv.n;
+        off += packed ? bytes : ((bytes + 15) & ~(size_t)15);
       }
       lv.frame_bytes = off;
-      if (lv.stored && !lv.packed) any_unpacked = true;
     }
     if (lv.stored) {
       const size_t bytes = (size_t)n_frames * lv.frame_bytes;
@@ -770,11 +742,9 @@ int phovo_engine_reserve_frames(phovo_engine *e, int n_frames, int width, int he
     if (e->cfg.blur_filter_size[l] > max_ks) max_ks = e->cfg.blur_filter_size[l];
   }
   hipError_t he = hipSuccess;        // raw-frame staging is allocated on first upload (ensure_stage)
-  {   // fp64 scratch: one staging chunk of planes where the producers cannot write straight into the pool (narrow storages,
-      // byte intensities), one frame for plane get/set otherwise
-    const size_t frames = any_unpacked ? (size_t)STAGE_CHUNK : 1;
+  {   // fp64 scratch: one staging chunk of planes for the narrow storages, one frame for plane get/set otherwise
+    const size_t frames = e->ext.plane_storage == PHOVO_STORAGE_F64 ? 1 : (size_t)STAGE_CHUNK;
     he = hipMalloc(&e->d_scratch, sizeof(double) * frames * PLANES_PER_FRAME * (max_n ? max_n : 1));
-    if (he == hipSuccess) he = hipMalloc(&e->d_flag, sizeof(int));
   }
   if (he == hipSuccess && max_ks > 0) {
     // (a level-0 blur runs at full resolution even when level 0 is not resident)
@@ -961,29 +931,13 @@ int phovo_engine_set_level_planes(phovo_engine *e, int frame, int level,
   const double *srcs[4] = {intensity, depth, grad_x, grad_y};
   for (int p = 0; p < 4; p++) {
     if (!srcs[p]) continue;
-    if (lv.elem[p] == ELEM_F64) {
+    if (e->ext.plane_storage == PHOVO_STORAGE_F64) {
       PHOVO_HIP_CHECK(hipMemcpyAsync(base + lv.plane_off[p], srcs[p], sizeof(double) * (size_t)lv.n,
                                      hipMemcpyHostToDevice, e->stream));
-    } else if (lv.elem[p] == ELEM_U8_UNIT) {
-      // the level keeps its intensities as bytes: the plane must be a converted 8-bit image, double(k) * (1./255) -- what
-      // SetSourceFrame / SetTargetFrame make of a frame (:471,484) and what OpenCV's own level 0 is -- or it is refused
-      // (stored first beside the pool, copied in only when every value is representable: nothing is half-written)
-      unsigned char *bytes = reinterpret_cast<unsigned char *>(e->d_scratch + lv.n);
-      PHOVO_HIP_CHECK(hipMemcpyAsync(e->d_scratch, srcs[p], sizeof(double) * (size_t)lv.n, hipMemcpyHostToDevice, e->stream));
-      PHOVO_HIP_CHECK(hipMemsetAsync(e->d_flag, 0, sizeof(int), e->stream));
-      PHOVO_HIP_CHECK(pyr_store_plane(e->d_scratch, 0, 1, lv.n, bytes, 0, ELEM_U8_UNIT, e->stream, e->d_flag));
-      int not_exact = 0;
-      PHOVO_HIP_CHECK(hipMemcpyAsync(&not_exact, e->d_flag, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-      PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
-      if (not_exact)
-        return fail(PHOVO_E_UNSUPPORTED, "set_level_planes: this level keeps its intensity plane as bytes (level 0 of a reference-exact "
-                                         "pool, phovo_hip.h: phovo_engine_set_level0_compaction) and the plane handed over is not a "
-                                         "converted 8-bit image (some value is not double(k) * (1./255)); switch the compaction off "
-                                         "before phovo_engine_reserve_frames to store arbitrary fp64 intensities");
-      PHOVO_HIP_CHECK(hipMemcpyAsync(base + lv.plane_off[p], bytes, (size_t)lv.n, hipMemcpyDeviceToDevice, e->stream));
     } else {                                   // round to the storage type on the device, like the producers do
       PHOVO_HIP_CHECK(hipMemcpyAsync(e->d_scratch, srcs[p], sizeof(double) * (size_t)lv.n, hipMemcpyHostToDevice, e->stream));
-      PHOVO_HIP_CHECK(pyr_store_plane(e->d_scratch, 0, 1, lv.n, base + lv.plane_off[p], lv.frame_bytes, lv.elem[p], e->stream));
+      PHOVO_HIP_CHECK(pyr_store_plane(e->d_scratch, 0, 1, lv.n, base + lv.plane_off[p], lv.frame_bytes,
+                                      e->ext.plane_storage, p == PLANE_D, e->stream));
       PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
     }
   }
@@ -1003,10 +957,10 @@ int phovo_engine_get_level_planes(const phovo_engine *e, int frame, int level,
   PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
   for (int p = 0; p < 4; p++) {
     if (!dsts[p]) continue;
-    if (lv.elem[p] == ELEM_F64) {
+    if (e->ext.plane_storage == PHOVO_STORAGE_F64) {
       PHOVO_HIP_CHECK(hipMemcpy(dsts[p], base + lv.plane_off[p], sizeof(double) * (size_t)lv.n, hipMemcpyDeviceToHost));
     } else {
-      PHOVO_HIP_CHECK(pyr_load_plane(base + lv.plane_off[p], lv.n, e->d_scratch, lv.elem[p], e->stream));
+      PHOVO_HIP_CHECK(pyr_load_plane(base + lv.plane_off[p], lv.n, e->d_scratch, e->ext.plane_storage, p == PLANE_D, e->stream));
       PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
       PHOVO_HIP_CHECK(hipMemcpy(dsts[p], e->d_scratch, sizeof(double) * (size_t)lv.n, hipMemcpyDeviceToHost));
     }
@@ -1157,7 +1111,6 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
     a.frame_bytes = lv.frame_bytes;
     for (int p = 0; p < PLANES_PER_FRAME; p++) a.plane_off[p] = lv.plane_off[p];
     a.huber_delta = e->ext.huber_delta[l];
-    a.intensity_u8 = lv.intensity_u8 ? 1 : 0;
     a.src = s.d_src; a.tgt = s.d_tgt;
     a.states = s.d_states; a.reports = s.d_reports;
     a.g_owner = s.d_owner;
@@ -1241,7 +1194,6 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
     } else {
       const bool few = few_batch && lv.plan_few_ok && lv.plan_few.owner_in_lds == lv.plan.owner_in_lds;
       const GNLaunchPlan &pl = few ? lv.plan_few : lv.plan;
-      const int kstorage = lv.intensity_u8 ? GN_STORAGE_F64_U8I : e->ext.plane_storage;      // (byte intensities: level 0, owner map in HBM)
       a.n_lds = pl.owner_in_lds ? 0 : pl.owner_lds_entries;
       a.g_mask = pl.mask_in_hbm ? s.d_mask : nullptr;
       a.depth_lds_chunks = pl.depth_lds_chunks;
@@ -1255,19 +1207,15 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
         // right behind it, which draws from that list.
         a.handover_out = list0;
         a.slide_m = gn_slide_reach_bands(lv.w, lv.h);
-        a.slide_touch = 2;
-#ifdef PHOVO_TUNING
-        if (const char *t = std::getenv("PHOVO_SLIDE_TOUCH")) a.slide_touch = std::atoi(t);
-#endif
-        PHOVO_HIP_CHECK(gn_launch_level_slide(a, kstorage, e->cu_count, s.stream));
+        PHOVO_HIP_CHECK(gn_launch_level_slide(a, e->ext.plane_storage, e->cu_count, s.stream));
         record(l, l, PHOVO_LAUNCH_SLIDE, gn_slide_threads(), (int)gn_slide_lds_bytes(), persistent_grid(1));
         a.handover_out = nullptr; a.handover_in = list0; a.takeover_flag = PHOVO_PAIR_WINDOW_FALLBACK;
         a.work_counter = heads1; a.n_queues = 1;
-        PHOVO_HIP_CHECK(gn_launch_level(a, pl, kstorage, e->cu_count, s.stream));
+        PHOVO_HIP_CHECK(gn_launch_level(a, pl, e->ext.plane_storage, e->cu_count, s.stream));
         record(l, l, PHOVO_LAUNCH_SLIDE_FALLBACK, pl.threads, pl.lds_bytes, persistent_grid(pl.wgs_per_cu));
         s.owner_tagged = true;                              // tagged entries stay behind (the kernel wipes per pair)
       } else {
-        PHOVO_HIP_CHECK(gn_launch_level(a, pl, kstorage, e->cu_count, s.stream));
+        PHOVO_HIP_CHECK(gn_launch_level(a, pl, e->ext.plane_storage, e->cu_count, s.stream));
         record(l, l, PHOVO_LAUNCH_PERSISTENT, pl.threads, pl.lds_bytes, persistent_grid(pl.wgs_per_cu));
         if (!pl.owner_in_lds) s.owner_tagged = true;
       }

@@ -240,42 +240,6 @@ __device__ __forceinline__ double plane_load<__half>(__amdgpu_buffer_rsrc_t r, i
   return (double)__half2float(__ushort_as_half(bits));
 }
 
-// ELEM_U8_UNIT (phovo_internal.hpp): the intensity k / 255 of a converted 8-bit image, stored as the byte k.  What
-// convertTo(., CV_64F, 1./255) wrote (...Analytic.h:471,484) is double(k) * (1./255) -- one conversion, one product, exact to
-// the bit -- and the product is made a value of its own (opaque to the optimiser): the residual I1 - I0 (:358) must subtract two
-// ROUNDED products, as the reference does, not fold one of them into a fused multiply-add.
-struct u8_unit { unsigned char k; };
-// A load and the use of its value are a chunk or a phase apart in every pixel loop (software prefetch): what travels in
-// between is the RAW word the load left (plane_fetch), and the conversion happens where the value is used (plane_value) -- a
-// conversion at the load would make the wave wait for the memory right there.  For the floating-point storages the raw word
-// already is the value (the widening is a plain cast the compiler places itself).
-template <typename T> struct plane_raw { typedef double type; };
-template <> struct plane_raw<u8_unit> { typedef unsigned type; };
-template <typename T>
-__device__ __forceinline__ typename plane_raw<T>::type plane_fetch(__amdgpu_buffer_rsrc_t r, int idx, int soff = 0)
-{
-  return plane_load<T>(r, idx, soff);
-}
-template <>
-__device__ __forceinline__ unsigned plane_fetch<u8_unit>(__amdgpu_buffer_rsrc_t r, int idx, int soff)
-{
-  return (unsigned)__builtin_amdgcn_raw_buffer_load_b8(r, idx, soff, 0);          // idx = -1 or past the plane: 0
-}
-template <typename T>
-__device__ __forceinline__ double plane_value(typename plane_raw<T>::type raw) { return raw; }
-template <>
-__device__ __forceinline__ double plane_value<u8_unit>(unsigned raw)
-{
-  double v = (double)raw * (1. / 255);
-  asm("" : "+v"(v));
-  return v;
-}
-template <>
-__device__ __forceinline__ double plane_load<u8_unit>(__amdgpu_buffer_rsrc_t r, int idx, int soff)
-{
-  return plane_value<u8_unit>(plane_fetch<u8_unit>(r, idx, soff));
-}
-
 // Elements idx and idx + 1 of a plane in ONE load (the two horizontal taps of a bilinear sample): 16 / 8 / 4 bytes.
 // Both elements must lie inside the plane.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));

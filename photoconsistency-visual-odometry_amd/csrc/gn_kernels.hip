@@ -74,9 +74,8 @@ struct LevelLds {
 // memory).  MASK_REG: the per-pixel "warped in bounds" flags of a lane live in one 64-bit register (needs <= 64 chunks
 // per wave), else in an LDS ballot array.  TI / TD: storage type of the intensity+gradient planes / of the depth plane
 // (double = reference-exact).  PARK (owner map in LDS, no SRC_LDS): whatever LDS the geometry leaves unused keeps the depth of
-// the image's leading A.depth_lds_chunks chunks from pass 1 to pass 2 (the block L.i0).  TP: storage type of the INTENSITY planes
-// where it differs from the gradients' (u8_unit: level 0 of a reference-exact pool, gn_device.hpp).
-template <int T, bool SRC_LDS, bool OWNER_LDS, bool MASK_REG, typename TI, typename TD, bool PARK = false, typename TP = TI>
+// the image's leading A.depth_lds_chunks chunks from pass 1 to pass 2 (the block L.i0).
+template <int T, bool SRC_LDS, bool OWNER_LDS, bool MASK_REG, typename TI, typename TD, bool PARK = false>
 __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds &L, const int pair, const bool state_in_lds,
                                            int &iteration, double &last_gnorm, int &last_valid)
 {
@@ -120,7 +119,7 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   }
   if (SRC_LDS) {
-    for (int k = tid; k < n; k += T) s_i0[k] = plane_load<TP>(rS, k, oI);
+    for (int k = tid; k < n; k += T) s_i0[k] = plane_load<TI>(rS, k, oI);
   }
   if (wave == 0) {
     double st[6];
@@ -358,8 +357,7 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
       // software prefetch, as in pass 1: owner + four planes of the NEXT chunk are requested (and the
       // gathered source intensity right behind them) before this chunk's arithmetic starts.
       int o_n = -1;
-      double pz_n = 0.0, gx_n = 0.0, gy_n = 0.0;
-      typename plane_raw<TP>::type i1_n = 0, i0_n = 0;      // (raw: converted where they are used, gn_device.hpp)
+      double pz_n = 0.0, gx_n = 0.0, gy_n = 0.0, i1_n = 0.0, i0_n = 0.0;
       // three constants that meet another scalar inside one fma sit in vector registers (an instruction reads one scalar
       // operand; the compiler otherwise copies them in front of every use: three v_mov_b64 per chunk)
       double oxv2 = oxi, oyv2 = oyi, cyv2 = cyy;
@@ -400,9 +398,9 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
         else pz_n = plane_load<TD>(rS, kk, oD);
         gx_n = plane_load<TI>(rT, kk, oGX);             // gradient at the SOURCE index  :346-347
         gy_n = plane_load<TI>(rT, kk, oGY);
-        i1_n = plane_fetch<TP>(rT, kk, oI);             // :309
+        i1_n = plane_load<TI>(rT, kk, oI);             // :309
         if (SRC_LDS) { if (o_n >= 0) i0_n = s_i0[o_n]; }
-        else i0_n = plane_fetch<TP>(rS, o_n, oI);       // :308 of the owning source pixel (o = -1: offset past the plane -> 0)
+        else i0_n = plane_load<TI>(rS, o_n, oI);       // :308 of the owning source pixel (o = -1: offset past the plane -> 0)
       };
       if (OWNER_LDS && my_chunks > 0) {
         o_ahead = s_owner[k];
@@ -413,15 +411,14 @@ __device__ __forceinline__ void level_body(const GNLevelArgs &A, const LevelLds 
       // `behind`: chunks of this wave that follow the one the body's fetch is for (wave-uniform)
       auto chunk_body = [&](const int chunk, auto next_parked_tag, const int behind) {
         const int o = o_n;
-        const double pz = pz_n, gxi = gx_n, gyi = gy_n;
-        const typename plane_raw<TP>::type raw2 = i1_n, raw1 = i0_n;
+        const double pz = pz_n, gxi = gx_n, gyi = gy_n, pixel2 = i1_n, pixel1 = i0_n;
         fetch(k + k_step, next_parked_tag, behind > 0);
         const unsigned long long mbits =
             MASK_REG ? (((unsigned long long)(unsigned)__builtin_amdgcn_readlane(inb_hi, j) << 32) |
                         (unsigned long long)(unsigned)__builtin_amdgcn_readlane(inb_lo, j))
                      : s_mask[chunk];
         if (__builtin_amdgcn_inverse_ballot_w64(mbits)) {                 // the ballot becomes the exec mask
-          const double res = (o >= 0) ? (plane_value<TP>(raw2) - plane_value<TP>(raw1)) : 0.0;          // :358
+          const double res = (o >= 0) ? (pixel2 - pixel1) : 0.0;          // :358
           PHOVO_ROWCOL_HERE
           const double px = fma(cd, ifx, oxv2) * pz;
           const double py = fma(rd, ify, oyv2) * pz;
@@ -650,7 +647,7 @@ __device__ __forceinline__ LevelLds carve_lds(unsigned char *lds_raw, int n_max,
 // The owner map in LDS is wiped ONCE per workgroup: pass 2 resets every slot it reads, and it reads all of them.
 // It is padded to whole chunks plus one round of the workgroup (owner_lds_entries): pass 2 fetches the owner a chunk
 // ahead without asking whether that chunk still exists -- the padding reads -1, "nobody", and pass 1 never writes there.
-template <int T, int WPS, bool SRC_LDS, bool OWNER_LDS, bool MASK_REG, typename TI, typename TD, bool PARK = false, typename TP = TI>
+template <int T, int WPS, bool SRC_LDS, bool OWNER_LDS, bool MASK_REG, typename TI, typename TD, bool PARK = false>
 __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
 {
   extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -674,7 +671,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel(const GNLevelArgs A)
     double last_gnorm = 0.0;
     int last_valid = 0;
     PHOVO_TIMELINE_BEGIN
-    level_body<T, SRC_LDS, OWNER_LDS, MASK_REG, TI, TD, PARK, TP>(A, L, pair, false, iteration, last_gnorm, last_valid);
+    level_body<T, SRC_LDS, OWNER_LDS, MASK_REG, TI, TD, PARK>(A, L, pair, false, iteration, last_gnorm, last_valid);
 
     // ---- epilogue: state and report back to HBM -------------------------------------------------
     if (tid == 0) {
@@ -774,8 +771,6 @@ enum Variant { V_TINY = 0, V_MID, V_WIDE, V_HUGE, V_QUAD, V_SOLO };
 #define PHOVO_KERNEL_QUAD(TI, TD)  gn_level_kernel<256, 4, false, true, true, TI, TD, true>
 #define PHOVO_KERNEL_SOLO(TI, TD)  gn_level_kernel<64, 4, false, true, true, TI, TD, true>
 #define PHOVO_KERNEL_FUSED(TI, TD) gn_fused_kernel<512, 4, TI, TD>
-// HUGE on a level whose intensity planes are bytes (GN_STORAGE_F64_U8I: level 0 of a reference-exact pool)
-#define PHOVO_KERNEL_HUGE_U8I      gn_level_kernel<1024, 4, false, false, false, double, double, false, u8_unit>
 
 }  // namespace
 
@@ -920,9 +915,6 @@ hipError_t launch_fused_storage(const GNFusedArgs &f, int n_blocks, hipStream_t 
 hipError_t gn_prepare_kernels()
 {
   hipError_t e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void *>(&PHOVO_KERNEL_HUGE_U8I), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)LDS_LIMIT);
-  if (e != hipSuccess) return e;
   if ((e = prepare_storage<double, double>()) != hipSuccess) return e;
   if ((e = prepare_storage<float, float>()) != hipSuccess) return e;
   return prepare_storage<__half, float>();
@@ -938,10 +930,6 @@ hipError_t gn_launch_level(const GNLevelArgs &a, const GNLaunchPlan &plan, int s
     case PHOVO_STORAGE_F64: return launch_storage<double, double>(a, plan, n_pairs, stream);
     case PHOVO_STORAGE_F32: return launch_storage<float, float>(a, plan, n_pairs, stream);
     case PHOVO_STORAGE_F16: return launch_storage<__half, float>(a, plan, n_pairs, stream);
-    case GN_STORAGE_F64_U8I:          // only levels whose owner map is in HBM keep their intensities as bytes (engine.cpp)
-      if (plan.variant != V_HUGE) return hipErrorInvalidValue;
-      hipLaunchKernelGGL(PHOVO_KERNEL_HUGE_U8I, dim3((unsigned)n_pairs), dim3((unsigned)plan.threads), (size_t)plan.lds_bytes, stream, a);
-      return hipGetLastError();
     default: return hipErrorInvalidValue;
   }
 }

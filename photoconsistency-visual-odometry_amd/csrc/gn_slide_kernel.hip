@@ -63,8 +63,7 @@ struct SlideGeom {
   static_assert((M_MAX + 2) * BAND_CHUNKS <= SLIDE_MASK_RING, "ballots of the bands between pass 1 and pass 2");
 };
 
-// TP: storage type of the intensity planes where it differs from the gradients' (u8_unit: level 0 of a reference-exact pool).
-template <int T, int NW1, int B1, int B2, typename TI, typename TD, typename TP = TI>
+template <int T, int NW1, int B1, int B2, typename TI, typename TD>
 __global__ __launch_bounds__(T, T / 256) void gn_level_kernel_slide(const GNLevelArgs A)
 {
   using G = SlideGeom<T, NW1, B1, B2>;
@@ -149,32 +148,9 @@ __global__ __launch_bounds__(T, T / 256) void gn_level_kernel_slide(const GNLeve
       double pzb[B1];
 #pragma unroll
       for (int b = 0; b < B1; b++) pzb[b] = plane_load<TD>(rS, k1 + b * STEP, oD);
-      // TOUCH AHEAD.  What pass 2 consumes in a phase it requested one phase earlier, and with every CU of the chip streaming a
-      // phase (~2 us of arithmetic) is shorter than the slowest of its ~150 loads takes to come back from HBM (~3 us: the
-      // workgroup waits at every phase barrier for the LAST load; profiles/r05_runs/residency_sweep_slide_kernel.txt: the same
-      // kernel runs a third faster per CU when only a quarter of the CUs stream).  Pass 2 has no registers for a second phase
-      // of operands; pass 1 has registers and issue slots to spare.  So each pass-1 wave touches -- one dword per 128-byte
-      // line -- one plane of the band pass 2 will request `touch` phases from now (wave 0: GX, 1: GY, 2: I1, 3: I0 around
-      // that band), which brings those lines into the XCD's L2 while there is still time; pass 2's own loads then come back
-      // at L2 latency.  The touched words are folded into a value nobody reads, two phases later.
-      const int touch = A.slide_touch;                                  // phases ahead (0: off)
-      const int t_plane = wave == 0 ? oGX : (wave == 1 ? oGY : oI);
-      const __amdgpu_buffer_rsrc_t rTouch = wave == 3 ? rS : rT;
-      constexpr int T_ELEM_TGT = (int)sizeof(TI), T_ELEM_I = (int)sizeof(TP);
-      const int t_elem = wave < 2 ? T_ELEM_TGT : T_ELEM_I;
-      const int t_lines = (BAND_PX * t_elem + 127) / 128;               // 128-byte lines of one band of that plane
-      unsigned t_new0 = 0, t_new1 = 0, t_mid0 = 0, t_mid1 = 0, t_fold = 0;
       for (int s = 0; s < n_bands; s++) {                               // wave-uniform trip count; no other branch in the body
         const int win_lo = (s - m_run + 1) * BAND_PX;
         const unsigned win_span = (unsigned)(2 * m_run * BAND_PX);
-        if (touch > 0 && wave < 4) {                                    // (wave-uniform)
-          t_fold ^= t_mid0 ^ t_mid1;
-          t_mid0 = t_new0; t_mid1 = t_new1;
-          const int tb = s - m_run + touch;                             // the band pass 2 requests `touch` phases from now
-          const int base = tb * BAND_PX * t_elem;                       // (before the image: negative -> out of range -> 0)
-          t_new0 = lane < t_lines ? __builtin_amdgcn_raw_buffer_load_b32(rTouch, base + lane * 128, t_plane, 0) : 0u;
-          t_new1 = lane + 64 < t_lines ? __builtin_amdgcn_raw_buffer_load_b32(rTouch, base + (lane + 64) * 128, t_plane, 0) : 0u;
-        }
 #pragma unroll
         for (int b = 0; b < B1; b++) {
           const double pz = pzb[b];                                     // :279
@@ -213,7 +189,6 @@ __global__ __launch_bounds__(T, T / 256) void gn_level_kernel_slide(const GNLeve
         __syncthreads();
       }
       for (int s = n_bands; s < n_phases; s++) __syncthreads();         // pass 2 finishes the last m + 1 bands
-      if ((t_fold ^ t_mid0 ^ t_mid1 ^ t_new0 ^ t_new1) == 0x9e3779b9u && lane == 65) s_ctl[CTL_OOW] ^= 0;      // (keeps the touched words alive; never true: lane < 64)
     } else {
       // ================= the waves of PASS 2: residual, Jacobian row, accumulation  (:308-356, 538-540) ===============
       const int wave2 = wave - NW1;
@@ -242,8 +217,7 @@ __global__ __launch_bounds__(T, T / 256) void gn_level_kernel_slide(const GNLeve
       int k2 = wave2 * WAVE + lane, chunk2 = wave2;
       double kd2 = (double)k2 + 0.5;
       int own_s[B2];
-      double pz_s[B2], gx_s[B2], gy_s[B2];
-      typename plane_raw<TP>::type i0_s[B2], i1_s[B2];       // (raw: converted where they are used, gn_device.hpp)
+      double i0_s[B2], pz_s[B2], gx_s[B2], gy_s[B2], i1_s[B2];
       auto request = [&](const int b, const int kk) {
         const int o = s_owner[kk & (SLIDE_RING_PX - 1)];                // (lanes past the image: a slot of a band long consumed)
         s_owner[kk & (SLIDE_RING_PX - 1)] = -1;
@@ -251,8 +225,8 @@ __global__ __launch_bounds__(T, T / 256) void gn_level_kernel_slide(const GNLeve
         pz_s[b] = plane_load<TD>(rS, kk, oD);
         gx_s[b] = plane_load<TI>(rT, kk, oGX);                          // gradient at the SOURCE index  :346-347
         gy_s[b] = plane_load<TI>(rT, kk, oGY);
-        i1_s[b] = plane_fetch<TP>(rT, kk, oI);                           // :309
-        i0_s[b] = plane_fetch<TP>(rS, o, oI);                            // :308 (owner -1: past the frame -> 0)
+        i1_s[b] = plane_load<TI>(rT, kk, oI);                           // :309
+        i0_s[b] = plane_load<TI>(rS, o, oI);                            // :308 (owner -1: past the frame -> 0)
       };
 #pragma unroll
       for (int b = 0; b < B2; b++) request(b, k2 + b * STEP);
@@ -267,15 +241,14 @@ __global__ __launch_bounds__(T, T / 256) void gn_level_kernel_slide(const GNLeve
 #pragma unroll
           for (int b = 0; b < B2; b++) {
             const int o = own_s[b];
-            const double pz = pz_s[b], gxi = gx_s[b], gyi = gy_s[b];
-            const typename plane_raw<TP>::type raw2 = i1_s[b], raw1 = i0_s[b];
+            const double pz = pz_s[b], gxi = gx_s[b], gyi = gy_s[b], pixel2 = i1_s[b], pixel1 = i0_s[b];
             request(b, k2 + B2 * STEP);                                 // this slot's chunk of the next band (final: see above)
             const unsigned long long mbits = s_mask[chunk2 & (SLIDE_MASK_RING - 1)];
             const unsigned long long mrow = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(mbits >> 32)) << 32) |
                                             (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)mbits);
             n_rows += __builtin_popcountll(mrow);
             if (__builtin_amdgcn_inverse_ballot_w64(mrow)) {
-              const double res = (o >= 0) ? (plane_value<TP>(raw2) - plane_value<TP>(raw1)) : 0.0;    // :358
+              const double res = (o >= 0) ? (pixel2 - pixel1) : 0.0;    // :358
               const double rd = trunc(kd2 * inv_w), cd = fma(-rd, dW, kd2);
               const double px = fma(cd, ifx, oxv2) * pz;
               const double py = fma(rd, ify, oyv2) * pz;
@@ -453,9 +426,6 @@ hipError_t gn_prepare_slide_kernels()
   PHOVO_PREP_SLIDE(PHOVO_SLIDE_GEOM, float, float)
   PHOVO_PREP_SLIDE(PHOVO_SLIDE_GEOM, __half, float)
 #undef PHOVO_PREP_SLIDE
-  e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gn_level_kernel_slide<PHOVO_SLIDE_GEOM, double, double, u8_unit>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)gn_slide_lds_bytes());
-  if (e != hipSuccess) return e;
   return hipSuccess;
 }
 
@@ -468,7 +438,6 @@ static hipError_t launch_slide_geom(const GNLevelArgs &a, int storage, int n_blo
     case PHOVO_STORAGE_F64: hipLaunchKernelGGL((gn_level_kernel_slide<T, NW1, B1, B2, double, double>), grid, block, lds, stream, a); break;
     case PHOVO_STORAGE_F32: hipLaunchKernelGGL((gn_level_kernel_slide<T, NW1, B1, B2, float, float>), grid, block, lds, stream, a); break;
     case PHOVO_STORAGE_F16: hipLaunchKernelGGL((gn_level_kernel_slide<T, NW1, B1, B2, __half, float>), grid, block, lds, stream, a); break;
-    case GN_STORAGE_F64_U8I: hipLaunchKernelGGL((gn_level_kernel_slide<T, NW1, B1, B2, double, double, u8_unit>), grid, block, lds, stream, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -219,8 +219,6 @@ __global__ __launch_bounds__(WT) void k_wide_pass1(const GNLevelArgs A, double *
   }
 }
 
-// TP: storage type of the intensity planes (double, or u8_unit on level 0 of a reference-exact pool: gn_device.hpp)
-template <typename TP>
 __global__ __launch_bounds__(WT) void k_wide_pass2(const GNLevelArgs A, const double *g_cst, const int *g_ctl,
                                                    const unsigned long long *g_mask, double *g_part, int tiles)
 {
@@ -233,9 +231,9 @@ __global__ __launch_bounds__(WT) void k_wide_pass2(const GNLevelArgs A, const do
   const PoseRegs P = load_pose(g_cst + (size_t)pair * 32);
   const unsigned char *src_frame = A.planes + (size_t)A.src[pair] * A.frame_bytes;
   const unsigned char *tgt_frame = A.planes + (size_t)A.tgt[pair] * A.frame_bytes;
-  const __amdgpu_buffer_rsrc_t rI0 = plane_rsrc<TP>(src_frame + A.plane_off[PLANE_I], n);
+  const __amdgpu_buffer_rsrc_t rI0 = plane_rsrc<double>(src_frame + A.plane_off[PLANE_I], n);
   const __amdgpu_buffer_rsrc_t rD0 = plane_rsrc<double>(src_frame + A.plane_off[PLANE_D], n);
-  const __amdgpu_buffer_rsrc_t rI1 = plane_rsrc<TP>(tgt_frame + A.plane_off[PLANE_I], n);
+  const __amdgpu_buffer_rsrc_t rI1 = plane_rsrc<double>(tgt_frame + A.plane_off[PLANE_I], n);
   const __amdgpu_buffer_rsrc_t rGX = plane_rsrc<double>(tgt_frame + A.plane_off[PLANE_GX], n);
   const __amdgpu_buffer_rsrc_t rGY = plane_rsrc<double>(tgt_frame + A.plane_off[PLANE_GY], n);
   int *g_owner = A.g_owner + (size_t)pair * (size_t)n;
@@ -253,8 +251,7 @@ __global__ __launch_bounds__(WT) void k_wide_pass2(const GNLevelArgs A, const do
   constexpr int CPW = TILE_CHUNKS / WNW;      // chunks per wave
   int os[CPW];
   unsigned long long ms[CPW];
-  double pzs[CPW], gxs[CPW], gys[CPW];
-  typename plane_raw<TP>::type i1s[CPW], i0s[CPW];
+  double pzs[CPW], gxs[CPW], gys[CPW], i1s[CPW], i0s[CPW];
 #pragma unroll
   for (int j = 0; j < CPW; j++) {
     const int chunk = blockIdx.x * TILE_CHUNKS + j * WNW + wave;
@@ -268,10 +265,10 @@ __global__ __launch_bounds__(WT) void k_wide_pass2(const GNLevelArgs A, const do
     pzs[j] = plane_load<double>(rD0, k);                                  // past the plane: 0
     gxs[j] = plane_load<double>(rGX, k);                                  // gradient at the SOURCE index  :346-347
     gys[j] = plane_load<double>(rGY, k);
-    i1s[j] = plane_fetch<TP>(rI1, k);                                     // :309
+    i1s[j] = plane_load<double>(rI1, k);                                  // :309
   }
 #pragma unroll
-  for (int j = 0; j < CPW; j++) i0s[j] = plane_fetch<TP>(rI0, os[j]);     // :308 (owner -1: past the plane -> 0)
+  for (int j = 0; j < CPW; j++) i0s[j] = plane_load<double>(rI0, os[j]);  // :308 (owner -1: past the plane -> 0)
 #pragma unroll
   for (int j = 0; j < CPW; j++) {                 // every slot is read once and made ready for the next pass 1
     const int k = (blockIdx.x * TILE_CHUNKS + j * WNW + wave) * WAVE + lane;
@@ -288,7 +285,7 @@ __global__ __launch_bounds__(WT) void k_wide_pass2(const GNLevelArgs A, const do
     if (!((m >> lane) & 1ull)) continue;
     const double pz = pzs[j];
     const double gxi = gxs[j], gyi = gys[j];
-    const double res = o >= 0 ? plane_value<TP>(i1s[j]) - plane_value<TP>(i0s[j]) : 0.0;       // :308-309,358
+    const double res = o >= 0 ? i1s[j] - i0s[j] : 0.0;                    // :308-309,358
     double cd, rd;
     rowcol_from_index((double)k, rc_map, cd, rd);
     const double px = (cd - ox) * pz * ifx;
@@ -402,8 +399,7 @@ hipError_t gn_run_level_wide(const GNLevelArgs &a, int n_pairs, void *workspace,
   int launched = 0;
   for (int it = 0; it < a.max_iter; it++) {
     hipLaunchKernelGGL(k_wide_pass1, grid, dim3(WT), 0, stream, a, g_cst, g_st, g_ctl, g_part, tiles, it, g_mask);
-    if (a.intensity_u8) hipLaunchKernelGGL(k_wide_pass2<u8_unit>, grid, dim3(WT), 0, stream, a, g_cst, g_ctl, g_mask, g_part, tiles);
-    else hipLaunchKernelGGL(k_wide_pass2<double>, grid, dim3(WT), 0, stream, a, g_cst, g_ctl, g_mask, g_part, tiles);
+    hipLaunchKernelGGL(k_wide_pass2, grid, dim3(WT), 0, stream, a, g_cst, g_ctl, g_mask, g_part, tiles);
     launched = it + 1;
     if (may_stop_early && it + 1 >= next_check && a.max_iter - (it + 1) >= 4) {     // a look costs about three empty iterations
       next_check = it + 1 + 8;

@@ -40,7 +40,6 @@ struct GNLevelArgs {
   int n_queues;             // 1: one queue for the whole grid; 8: one per XCD over a contiguous eighth of the pairs (+ stealing)
   int n_lds;                // owner map in HBM only: its first n_lds entries (a multiple of 64) live in LDS instead
   int slide_m;              // sliding-window kernel: bands a target may lie away from its source's band (gn_slide_reach_bands)
-  int slide_touch;          // sliding-window kernel: its pass-1 waves touch the target planes this many phases ahead of pass 2's request (0: off)
   int depth_lds_chunks;     // owner map in LDS: the depth of the first this-many 64-pixel chunks is kept in leftover LDS by pass 1
                             // and read from there by pass 2 (0: none)
   // Hand-over of pairs from the sliding-window launch of a level to the exact launch right behind it (same stream).  A
@@ -52,7 +51,6 @@ struct GNLevelArgs {
   const int *handover_in;
   int *handover_out;
   unsigned takeover_flag;
-  int intensity_u8;         // wide form: the intensity planes of this level are ELEM_U8_UNIT
 };
 
 // Several consecutive levels of one launch (gn_fused_kernel): lv[0] is the coarsest.  The pair list, states, reports and
@@ -127,21 +125,12 @@ hipError_t pyr_depth_level_u16(const uint16_t *depth, size_t src_frame_stride, d
                                hipStream_t stream);
 hipError_t pyr_scharr(const double *base, size_t frame_stride, size_t img_off, size_t gx_off, size_t gy_off,
                       int frames, int w, int h, double scale, hipStream_t stream);
-// Element type of a stored plane.  ELEM_U8_UNIT: an intensity k / 255 kept as the byte k -- level 0 of a reference-exact pool
-// whose owner map does not fit LDS (the launches that stream from HBM): the value convertTo(., CV_64F, 1./255) produces
-// (...Analytic.h:471,484) is double(k) * (1./255), rebuilt exactly on load, 1 byte instead of 8 for two of the five planes a
-// pixel-iteration reads.
-enum Elem { ELEM_F64 = 0, ELEM_F32 = 1, ELEM_F16 = 2, ELEM_U8_UNIT = 3 };
-int storage_elem(int storage, int plane);      // element type of `plane` under PHOVO_STORAGE_* (without the level-0 compaction)
-size_t elem_size(int elem);
-// fp64 <-> stored-type plane conversion.  not_exact (ELEM_U8_UNIT only, may be null): device int, OR-ed with 1 when a value is
-// not double(k) * (1./255) for a byte k.
+// fp64 <-> storage-type plane conversion (storage = PHOVO_STORAGE_*, is_depth selects the depth element type).
+size_t storage_elem_size(int storage, bool is_depth);
 hipError_t pyr_store_plane(const double *src, size_t src_frame_stride, int frames, int n, unsigned char *dst,
-                           size_t dst_frame_bytes, int elem, hipStream_t stream, int *not_exact = nullptr);
-hipError_t pyr_load_plane(const unsigned char *src, int n, double *dst, int elem, hipStream_t stream);
-// Internal storage code of the Gauss-Newton launches: PHOVO_STORAGE_* or, for a level whose intensity plane is ELEM_U8_UNIT
-// (fp64 depth and gradients), this one.
-constexpr int GN_STORAGE_F64_U8I = 3;
+                           size_t dst_frame_bytes, int storage, bool is_depth, hipStream_t stream);
+hipError_t pyr_load_plane(const unsigned char *src, int n, double *dst, int storage, bool is_depth,
+                          hipStream_t stream);
 hipError_t pyr_gaussian_blur(double *img, double *tmp, int w, int h, int ksize,
                              const double *d_kernel, hipStream_t stream);
 hipError_t fill_i32(int *dst, size_t n, int value, hipStream_t stream);

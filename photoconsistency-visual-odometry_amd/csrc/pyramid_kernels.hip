@@ -163,29 +163,6 @@ __device__ __forceinline__ double get(const double *p) { return *p; }
 __device__ __forceinline__ double get(const float *p) { return (double)*p; }
 __device__ __forceinline__ double get(const __half *p) { return (double)__half2float(*p); }
 
-// Level-0 intensities of a reference-exact pool are the frame's bytes themselves (ELEM_U8_UNIT): convertTo(., CV_64F, 1./255)
-// (...Analytic.h:471,484) makes them double(k) * (1./255), which the Gauss-Newton kernels rebuild from k on load, bit for
-// bit.  Storing: k = rint(v * 255), and *not_exact is raised when double(k) * (1./255) is not v again (a plane handed over by the
-// caller that is not a converted 8-bit image: phovo_engine_set_level_planes refuses it).
-__global__ __launch_bounds__(256) void k_store_plane_u8(const double *src_base, size_t src_frame_stride, int n,
-                                                        unsigned char *dst_base, size_t dst_frame_bytes, int *not_exact)
-{
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const double v = src_base[(size_t)blockIdx.z * src_frame_stride + i];
-  double k = rint(v * 255.0);
-  k = k < 0.0 ? 0.0 : (k > 255.0 ? 255.0 : k);       // (NaN fails both comparisons and converts to 0)
-  const unsigned char b = (unsigned char)(int)k;
-  dst_base[(size_t)blockIdx.z * dst_frame_bytes + i] = b;
-  if (not_exact && !((double)b * (1. / 255) == v)) atomicOr(not_exact, 1);
-}
-
-__global__ __launch_bounds__(256) void k_load_plane_u8(const unsigned char *src, int n, double *dst)
-{
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[i] = (double)src[i] * (1. / 255);
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void k_store_plane(const double *src_base, size_t src_frame_stride, int n,
                                                      unsigned char *dst_base, size_t dst_frame_bytes)
@@ -243,47 +220,31 @@ hipError_t pyr_scharr(const double *base, size_t frame_stride, size_t img_off, s
   return hipGetLastError();
 }
 
-int storage_elem(int storage, int plane)
+size_t storage_elem_size(int storage, bool is_depth)
 {
-  if (storage == PHOVO_STORAGE_F32) return ELEM_F32;
-  if (storage == PHOVO_STORAGE_F16) return plane == PLANE_D ? ELEM_F32 : ELEM_F16;
-  return ELEM_F64;
-}
-
-size_t elem_size(int elem)
-{
-  switch (elem) {
-    case ELEM_F32: return 4;
-    case ELEM_F16: return 2;
-    case ELEM_U8_UNIT: return 1;
-    default: return 8;
-  }
+  if (storage == PHOVO_STORAGE_F32) return 4;
+  if (storage == PHOVO_STORAGE_F16) return is_depth ? 4 : 2;
+  return 8;
 }
 
 hipError_t pyr_store_plane(const double *src, size_t src_frame_stride, int frames, int n, unsigned char *dst,
-                           size_t dst_frame_bytes, int elem, hipStream_t stream, int *not_exact)
+                           size_t dst_frame_bytes, int storage, bool is_depth, hipStream_t stream)
 {
   const dim3 grid((unsigned)((n + 255) / 256), 1, (unsigned)frames);
-  switch (elem) {
-    case ELEM_F64: hipLaunchKernelGGL(k_store_plane<double>, grid, dim3(256), 0, stream, src, src_frame_stride, n, dst, dst_frame_bytes); break;
-    case ELEM_F32: hipLaunchKernelGGL(k_store_plane<float>, grid, dim3(256), 0, stream, src, src_frame_stride, n, dst, dst_frame_bytes); break;
-    case ELEM_F16: hipLaunchKernelGGL(k_store_plane<__half>, grid, dim3(256), 0, stream, src, src_frame_stride, n, dst, dst_frame_bytes); break;
-    case ELEM_U8_UNIT: hipLaunchKernelGGL(k_store_plane_u8, grid, dim3(256), 0, stream, src, src_frame_stride, n, dst, dst_frame_bytes, not_exact); break;
-    default: return hipErrorInvalidValue;
-  }
+  const size_t es = storage_elem_size(storage, is_depth);
+  if (es == 8) hipLaunchKernelGGL(k_store_plane<double>, grid, dim3(256), 0, stream, src, src_frame_stride, n, dst, dst_frame_bytes);
+  else if (es == 4) hipLaunchKernelGGL(k_store_plane<float>, grid, dim3(256), 0, stream, src, src_frame_stride, n, dst, dst_frame_bytes);
+  else hipLaunchKernelGGL(k_store_plane<__half>, grid, dim3(256), 0, stream, src, src_frame_stride, n, dst, dst_frame_bytes);
   return hipGetLastError();
 }
 
-hipError_t pyr_load_plane(const unsigned char *src, int n, double *dst, int elem, hipStream_t stream)
+hipError_t pyr_load_plane(const unsigned char *src, int n, double *dst, int storage, bool is_depth, hipStream_t stream)
 {
   const dim3 grid((unsigned)((n + 255) / 256));
-  switch (elem) {
-    case ELEM_F64: hipLaunchKernelGGL(k_load_plane<double>, grid, dim3(256), 0, stream, src, n, dst); break;
-    case ELEM_F32: hipLaunchKernelGGL(k_load_plane<float>, grid, dim3(256), 0, stream, src, n, dst); break;
-    case ELEM_F16: hipLaunchKernelGGL(k_load_plane<__half>, grid, dim3(256), 0, stream, src, n, dst); break;
-    case ELEM_U8_UNIT: hipLaunchKernelGGL(k_load_plane_u8, grid, dim3(256), 0, stream, src, n, dst); break;
-    default: return hipErrorInvalidValue;
-  }
+  const size_t es = storage_elem_size(storage, is_depth);
+  if (es == 8) hipLaunchKernelGGL(k_load_plane<double>, grid, dim3(256), 0, stream, src, n, dst);
+  else if (es == 4) hipLaunchKernelGGL(k_load_plane<float>, grid, dim3(256), 0, stream, src, n, dst);
+  else hipLaunchKernelGGL(k_load_plane<__half>, grid, dim3(256), 0, stream, src, n, dst);
   return hipGetLastError();
 }
 

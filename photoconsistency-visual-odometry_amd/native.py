@@ -122,7 +122,6 @@ SYMBOLS = {
     "phovo_engine_set_intrinsic_matrix": (C.c_int, [_vp, _dp]),
     "phovo_engine_set_depth_range": (C.c_int, [_vp, C.c_double, C.c_double]),
     "phovo_engine_set_build_all_levels": (C.c_int, [_vp, C.c_int]),
-    "phovo_engine_set_level0_compaction": (C.c_int, [_vp, C.c_int]),
     "phovo_engine_set_wide_policy": (C.c_int, [_vp, C.c_int]),
     "phovo_engine_set_level_fusion": (C.c_int, [_vp, C.c_int]),
     "phovo_engine_set_batch_invariant": (C.c_int, [_vp, C.c_int]),

@@ -204,11 +204,6 @@ class AlignmentEngine:
         check(self._lib.phovo_engine_set_depth_range(self._h, float(min_depth), float(max_depth)),
               "phovo_engine_set_depth_range")
 
-    def set_level0_compaction(self, on=True):
-        """Level 0 of a reference-exact pool that streams from HBM keeps its intensity plane as bytes (exact; default on);
-        off: fp64 intensities everywhere, arbitrary planes accepted by set_level_planes.  Drops the frame pool."""
-        check(self._lib.phovo_engine_set_level0_compaction(self._h, 1 if on else 0), "phovo_engine_set_level0_compaction")
-
     def set_build_all_levels(self, on):
         check(self._lib.phovo_engine_set_build_all_levels(self._h, int(bool(on))), "phovo_engine_set_build_all_levels")
 

@@ -323,69 +323,6 @@ def _render_pair_with_motion(seed, w, h, motion, holes=0.02):
     return dict(gray0=g0, depth0=d0, gray1=g1, depth1=d1, K=K, motion=np.array(motion))
 
 
-@pytest.mark.parametrize("size", [(640, 480), (330, 250)])
-def test_level0_byte_intensities_change_no_bit(size):
-    """Level 0 of a reference-exact pool whose owner map does not fit LDS keeps its intensity plane as the frame's bytes
-    (phovo_engine_set_level0_compaction, default on): convertTo's double(k) * (1./255) (...Analytic.h:471,484) is rebuilt on
-    load.  With the compaction on and off, on every form that reads such a level -- the sliding-window kernel, the exact kernel
-    behind it (owner map in HBM), the wide form -- states, iteration counts, gradient norms and valid-pixel counts are equal
-    BIT FOR BIT, equal to the oracle's, and get_level_planes returns the same fp64 planes; a plane set from outside is taken
-    when it is a converted 8-bit image and refused (nothing written) when it is not; with a level-0 blur or a smaller level 0
-    nothing is compacted."""
-    w, h = size
-    probs = [synthetic.make_pair(90 + i, w, h, holes=0.02, trans=0.008 * (i + 1), rot=0.003 * (i + 1)) for i in range(3)]
-    ncfg, ocfg = _cfgs(1, [6], [0.0])
-    expect = [oracle.align_frames(ocfg, p["K"], p["gray0"], p["depth0"], p["gray1"]) for p in probs]
-    src48, tgt48 = [2 * (k % 3) for k in range(48)], [2 * (k % 3) + 1 for k in range(48)]
-    out, planes = {}, {}
-    for compact in (True, False):
-        with odometry.AlignmentEngine() as eng:
-            eng.set_level0_compaction(compact)
-            eng.set_config(ncfg)
-            eng.set_intrinsic_matrix(probs[0]["K"])
-            eng.reserve_frames(6, w, h)
-            assert not eng.level_launch_info(0)["owner_in_lds"]
-            for i, p in enumerate(probs):
-                eng.upload_frame(2 * i, p["gray0"], p["depth0"], roles=native.ROLE_SOURCE)
-                eng.upload_frame(2 * i + 1, p["gray1"], None, roles=native.ROLE_TARGET)
-            planes[compact] = [eng.get_level_planes(f, 0) for f in range(6)]
-            res = {}
-            res["slide"] = eng.align_pairs(src48, tgt48, want_reports=True)
-            assert [r["kind"] for r in eng.last_launches()] == ["slide", "slide_fallback"]
-            eng.set_slide_policy(-1)
-            res["exact"] = eng.align_pairs(src48, tgt48, want_reports=True)
-            assert [r["kind"] for r in eng.last_launches()] == ["persistent"]
-            eng.set_slide_policy(0)
-            res["wide"] = eng.align_pairs([0, 2, 4], [1, 3, 5], want_reports=True)
-            assert [r["kind"] for r in eng.last_launches()] == ["wide"]
-            out[compact] = res
-            # a plane from outside: a converted 8-bit image is taken as it is (round trip), anything else is refused
-            i1 = planes[compact][1][0]
-            eng.set_level_planes(3, 0, intensity=i1)
-            assert np.array_equal(eng.get_level_planes(3, 0)[0], i1)
-            arbitrary = i1 + 1e-9
-            if compact:
-                with pytest.raises(native.PhovoError) as err:
-                    eng.set_level_planes(3, 0, intensity=arbitrary)
-                assert err.value.status == native.E_UNSUPPORTED
-                assert np.array_equal(eng.get_level_planes(3, 0)[0], i1)        # nothing was written
-            else:
-                eng.set_level_planes(3, 0, intensity=arbitrary)
-                assert np.array_equal(eng.get_level_planes(3, 0)[0], arbitrary)
-    for f in range(6):
-        for a, b in zip(planes[True][f], planes[False][f]):
-            assert np.array_equal(a, b)
-    for form in ("slide", "exact", "wide"):
-        (sa, ra), (sb, rb) = out[True][form], out[False][form]
-        assert np.array_equal(sa, sb), form
-        for x, y in zip(ra, rb):
-            assert list(x.iterations[:1]) == list(y.iterations[:1]) and x.gradient_norm == y.gradient_norm and x.flags == y.flags
-            assert list(x.valid_pixels[:1]) == list(y.valid_pixels[:1])
-        for k in range(len(sa)):
-            es, eits = expect[k % 3]
-            assert list(ra[k].iterations[:1]) == eits and se3.state_distance(sa[k], es) < POSE_TOL, (form, k)
-
-
 @pytest.mark.parametrize("size,iters", [((320, 240), 9), ((640, 480), 4), ((330, 250), 5)])
 def test_sliding_window_kernel_matches_exact_kernel_and_oracle(size, iters):
     """Levels whose owner map exceeds LDS: the sliding-window kernel (owner ring in LDS, gn_slide_kernel.hip) against the
@@ -874,7 +811,6 @@ def test_exact_half_pixel_projections_on_the_device(sign, size, pairs):
     es, eits = oracle.optimize(ocfg, K, [i0], [d0], [i1], [gx], [gy], init_state=state)
     assert eits == [1] and np.all(np.isfinite(es)) and np.linalg.norm(es - state) > 1e-6
     with odometry.AlignmentEngine() as eng:
-        eng.set_level0_compaction(False)          # random fp64 intensities, not a converted 8-bit image (320x240 would keep bytes)
         eng.set_config(ncfg)
         eng.set_intrinsic_matrix(K)
         eng.reserve_frames(2, w, h)
