@@ -43,6 +43,7 @@ struct LevelPool {
   unsigned char *planes = nullptr;   // frame f at planes + f*frame_bytes, plane p of it at + plane_off[p]
   size_t frame_bytes = 0;
   size_t plane_off[PLANES_PER_FRAME] = {0, 0, 0, 0};
+  size_t rec_off = 0;                  // bilinear sampling: the frame's tap records {I, GX, GY, pad} behind its planes (0: none)
   GNLaunchPlan plan{};
   bool plan_ok = false;
   GNLaunchPlan plan_few{};             // geometry for a handful of pairs (LATENCY_PAIRS or fewer)
@@ -314,9 +315,8 @@ int build_pyramids(phovo_engine *e, int first_frame, int count, int roles, Depth
     // fp64 storage: the producers write straight into the pool.  Narrow storage: they write fp64 planes into
     // the scratch chunk (same [frame][4][n] layout) and a convert pass rounds them into the pool once.
     const size_t fstride = (size_t)PLANES_PER_FRAME * (size_t)lv.n;
-    double *base = storage == PHOVO_STORAGE_F64
-                       ? reinterpret_cast<double *>(lv.planes + (size_t)first_frame * lv.frame_bytes)
-                       : e->d_scratch;
+    const bool direct = storage == PHOVO_STORAGE_F64 && lv.rec_off == 0;
+    double *base = direct ? reinterpret_cast<double *>(lv.planes + (size_t)first_frame * lv.frame_bytes) : e->d_scratch;
     // BuildPyramid(intensity, applyBlur = true)  :474,487
     const int ks = e->cfg.blur_filter_size[l];
     const double *kern = ks > 0 ? e->d_blur_kernel + (size_t)l * e->blur_kernel_stride : nullptr;
@@ -348,7 +348,7 @@ int build_pyramids(phovo_engine *e, int first_frame, int count, int roles, Depth
       PHOVO_HIP_CHECK(pyr_scharr(base, fstride, (size_t)PLANE_I * lv.n, (size_t)PLANE_GX * lv.n,
                                  (size_t)PLANE_GY * lv.n, count, lv.w, lv.h,
                                  e->cfg.image_gradients_scaling_factor[l], e->stream));
-    if (storage != PHOVO_STORAGE_F64) {
+    if (!direct) {
       unsigned char *dst = lv.planes + (size_t)first_frame * lv.frame_bytes;
       const bool want[PLANES_PER_FRAME] = {true, (roles & PHOVO_ROLE_SOURCE) != 0, (roles & PHOVO_ROLE_TARGET) != 0,
                                            (roles & PHOVO_ROLE_TARGET) != 0};
@@ -358,6 +358,9 @@ int build_pyramids(phovo_engine *e, int first_frame, int count, int roles, Depth
                                         lv.frame_bytes, storage, p == PLANE_D, e->stream));
       }
     }
+    if (lv.rec_off && (roles & PHOVO_ROLE_TARGET))                      // bilinear sampling: the target's tap records
+      PHOVO_HIP_CHECK(pyr_build_tap_records(lv.planes + (size_t)first_frame * lv.frame_bytes, lv.frame_bytes, lv.plane_off,
+                                            lv.rec_off, count, lv.n, storage, e->stream));
   }
   return PHOVO_OK;
 }
@@ -565,7 +568,10 @@ int phovo_engine_set_extensions(phovo_engine *e, const phovo_extensions *ext)
                                      "(the scatter path is kept reference-exact)");
   for (int l = 0; l < PHOVO_MAX_LEVELS; l++)
     if (!(ext->huber_delta[l] == ext->huber_delta[l])) return fail(PHOVO_E_INVALID_ARGUMENT, "set_extensions: huber_delta is NaN");
-  if (ext->plane_storage != e->ext.plane_storage) {      // the pool layout changes
+  // the pool layout changes with the storage type, and -- fp16 planes under bilinear sampling carry tap records -- with the
+  // sampling where that adds or removes the records
+  auto has_records = [](const phovo_extensions &x) { return x.sampling == PHOVO_SAMPLING_BILINEAR && x.plane_storage == PHOVO_STORAGE_F16; };
+  if (ext->plane_storage != e->ext.plane_storage || has_records(*ext) != has_records(e->ext)) {
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
     (void)quiesce(e);
@@ -722,12 +728,22 @@ int phovo_engine_reserve_frames(phovo_engine *e, int n_frames, int width, int he
     lv.plan_few_ok = gn_plan_level(lv.n, &lv.plan_few, 1, fp64_planes);
     {   // byte layout of one frame at this level: planes I, D, GX, GY.  fp64: packed [4][n] doubles, which is
         // what the producer kernels write directly; narrow storages: every plane starts 16-byte aligned.
-      const bool packed = e->ext.plane_storage == PHOVO_STORAGE_F64;
+      // Bilinear sampling (extension): behind the planes every frame carries its tap records (pyr_build_tap_records), so
+      // the frame is no longer what the producers write in one piece.
+      const bool records = e->ext.sampling == PHOVO_SAMPLING_BILINEAR && e->ext.plane_storage == PHOVO_STORAGE_F16;      // (fp16 planes only: gn_bilinear_kernel.hip)
+      const bool packed = e->ext.plane_storage == PHOVO_STORAGE_F64 && !records;
       size_t off = 0;
       for (int p = 0; p < PLANES_PER_FRAME; p++) {
         lv.plane_off[p] = off;
         const size_t bytes = storage_elem_size(e->ext.plane_storage, p == PLANE_D) * (size_t)lv.n;
         off += packed ? bytes : ((bytes + 15) & ~(size_t)15);
+      }
+      lv.rec_off = 0;
+      if (records) {
+        off = (off + 31) & ~(size_t)31;
+        lv.rec_off = off;
+        off += 4 * storage_elem_size(e->ext.plane_storage, false) * (size_t)lv.n;
+        off = (off + 31) & ~(size_t)31;
       }
       lv.frame_bytes = off;
     }
@@ -941,6 +957,9 @@ int phovo_engine_set_level_planes(phovo_engine *e, int frame, int level,
       PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
     }
   }
+  if (lv.rec_off && (intensity || grad_x || grad_y))                    // bilinear sampling: this frame's tap records follow its planes
+    PHOVO_HIP_CHECK(pyr_build_tap_records(lv.planes + (size_t)frame * lv.frame_bytes, lv.frame_bytes, lv.plane_off, lv.rec_off,
+                                          1, lv.n, e->ext.plane_storage, e->stream));
   PHOVO_HIP_CHECK(hipStreamSynchronize(e->stream));
   return PHOVO_OK;
 }
@@ -1111,6 +1130,7 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
     a.frame_bytes = lv.frame_bytes;
     for (int p = 0; p < PLANES_PER_FRAME; p++) a.plane_off[p] = lv.plane_off[p];
     a.huber_delta = e->ext.huber_delta[l];
+    a.rec_off = lv.rec_off;
     a.src = s.d_src; a.tgt = s.d_tgt;
     a.states = s.d_states; a.reports = s.d_reports;
     a.g_owner = s.d_owner;

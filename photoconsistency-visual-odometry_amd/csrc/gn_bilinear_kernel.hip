@@ -1,12 +1,12 @@
 // EXTENSION, NOT IN THE REFERENCE'S ANALYTIC PATH (PHOVO_SAMPLING_BILINEAR): forward-additive alignment with bilinear
 // sampling, taps gathered from global memory (any level size), 256 threads x 2 workgroups per CU.
-// Measured and not kept (round 4, profiles/r04_runs/bilinear_lds_ab.txt; the code is in the history): the target's I1 / GX / GY
-// rows staged in LDS -- the whole level when it fits (80x60 fp64, 160x120 fp16: 115 KB), a ring of rows sliding down the
-// image otherwise -- with 768 threads and one workgroup per CU.  With the whole level resident it ran exactly as fast as
-// this kernel (80x60 fp64: 16.8 against 16.8 ms per 8192 pairs x 50 iterations, 169 against 152 vector instructions per
-// chunk): the taps are not what bounds it -- two workgroups per CU hide each other's gathers and serial sections, one
-// workgroup of 12 waves has nobody to hide its solve behind -- and the sliding ring (a barrier and a row prefetch per 768
-// pixels) was 2.5x slower.
+// Round 5, fp16 planes only: a tap is ONE RECORD {I, GX, GY, pad} of the target frame -- 8 bytes, one load -- instead of three
+// 2-byte gathers from three planes (pyr_build_tap_records keeps the records behind the planes, same bits): 4 loads per pixel
+// where there were 12, 186-196 k -> 224 k alignments/s (+14 %).  The same records on fp32 planes (16 bytes, 4 loads instead
+// of 6 pair loads) lost 5 %, on fp64 planes (32 bytes: a 16- and an 8-byte load per tap, 8 instead of 12) changed nothing
+// (178.1 k against 178.3 k: 80x60 5 % faster, 160x120 3 % slower): it is not the NUMBER of loads that holds this kernel at
+// 0.54 on fp64 planes, and more bytes per tap cost what fewer instructions buy (profiles/r05_runs/bilinear_records_ab.txt).
+// Those two storages keep their gathers.
 // Also measured and not kept (round 4, profiles/r04_runs/bilinear_roles_ab.txt): two kinds of waves as in the sliding-window
 // kernel -- samplers (warp, taps, interpolation) leave depth, 1/Z', residual and both gradients in LDS, accumulators build
 // the Jacobian row and the 27 sums a band later.  Parity-green; 512 threads x 2 per CU with one chunk of taps in flight per
@@ -22,6 +22,18 @@
 namespace phovo_hip {
 
 namespace {
+
+// One tap record {I, GX, GY, pad} as the load leaves it in registers; the three values are widened where they are used.
+template <typename T> struct tap_rec;
+template <> struct tap_rec<double> { };                              // (fp64 / fp32 planes keep their gathers: see above)
+template <> struct tap_rec<float> { };
+template <> struct tap_rec<__half> {                                  // 8 bytes: one load
+  u32x2 a;
+  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, int idx) { a = __builtin_amdgcn_raw_buffer_load_b64(r, idx * 8, 0, 0); }
+  __device__ __forceinline__ double i() const { return (double)__half2float(__ushort_as_half((unsigned short)(a.x & 0xffffu))); }
+  __device__ __forceinline__ double gx() const { return (double)__half2float(__ushort_as_half((unsigned short)(a.x >> 16))); }
+  __device__ __forceinline__ double gy() const { return (double)__half2float(__ushort_as_half((unsigned short)(a.y & 0xffffu))); }
+};
 
 // EXTENSION, NOT IN THE REFERENCE'S ANALYTIC PATH (PHOVO_SAMPLING_BILINEAR): forward-additive alignment with
 // bilinear sampling.  Every valid source pixel i is warped to the real-valued (tr, tc); the target intensity and
@@ -56,6 +68,8 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel_bilinear(const GNLevel
   const unsigned char *tgt_frame = A.planes + (size_t)A.tgt[pair] * A.frame_bytes;
   const __amdgpu_buffer_rsrc_t rI0 = plane_rsrc<TI>(src_frame + A.plane_off[PLANE_I], n);
   const __amdgpu_buffer_rsrc_t rD0 = plane_rsrc<TD>(src_frame + A.plane_off[PLANE_D], n);
+  constexpr bool REC = sizeof(TI) == 2;             // fp16 planes: taps come from the target's records {I, GX, GY, pad}
+  const __amdgpu_buffer_rsrc_t rRec = plane_rsrc<TI>(tgt_frame + (REC ? A.rec_off : 0), REC ? 4 * n : 0);
   const __amdgpu_buffer_rsrc_t rI1 = plane_rsrc<TI>(tgt_frame + A.plane_off[PLANE_I], n);
   const __amdgpu_buffer_rsrc_t rGX = plane_rsrc<TI>(tgt_frame + A.plane_off[PLANE_GX], n);
   const __amdgpu_buffer_rsrc_t rGY = plane_rsrc<TI>(tgt_frame + A.plane_off[PLANE_GY], n);
@@ -111,7 +125,8 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel_bilinear(const GNLevel
     // Two register sets alternate (no copies); the arithmetic of a pixel is unchanged.
     struct Warped {
       double px, py, pz, Zr, t25, ax, ay, i0;
-      double tap[12];                       // I1, GX, GY x (p00, p01, p10, p11)
+      tap_rec<TI> rec[REC ? 4 : 1];         // REC: the records at p00, p01, p10, p11
+      double tap[REC ? 1 : 12];             // else: I1, GX, GY x (p00, p01, p10, p11)
       unsigned long long m;                 // lanes that are valid and land in bounds
     };
     int k = k0;
@@ -146,6 +161,12 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel_bilinear(const GNLevel
         w.ay = tr - fr;
         const int ic = (int)fc, ir = (int)fr;
         const int r0w = __mul24(max(ir, 0), W), r1w = __mul24(min(ir + 1, H - 1), W);
+        if constexpr (REC) {
+          // clamp-to-edge taps (in the outer half-pixel band both taps of a row / a column are the edge pixel)
+          const int c0i = max(ic, 0), c1i = min(ic + 1, W - 1);
+          w.rec[0].load(rRec, r0w + c0i); w.rec[1].load(rRec, r0w + c1i);
+          w.rec[2].load(rRec, r1w + c0i); w.rec[3].load(rRec, r1w + c1i);
+        } else
         if (sizeof(TI) < sizeof(double) && W >= 2) {                      // (compile-time and wave-uniform)
           // Narrow plane storages: the two horizontal taps of a row are neighbours in memory and go out as a PAIR -- one
           // 8-byte load for two fp32 taps, one address for two fp16 taps (fp32 planes 99 -> 176 k alignments/s, fp16
@@ -185,12 +206,19 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel_bilinear(const GNLevel
       n_rows += __builtin_popcountll(w.m);
       if (__builtin_amdgcn_inverse_ballot_w64(w.m)) {
         const double px = w.px, py = w.py, pz = w.pz, Zr = w.Zr, t25 = w.t25, ax = w.ax, ay = w.ay;
-        auto sample = [&](int b) {
-          const double p00 = w.tap[b], p01 = w.tap[b + 1], p10 = w.tap[b + 2], p11 = w.tap[b + 3];
+        auto sample = [&](double p00, double p01, double p10, double p11) {
           return (1.0 - ay) * ((1.0 - ax) * p00 + ax * p01) + ay * ((1.0 - ax) * p10 + ax * p11);
         };
-        const double res = sample(0) - w.i0;
-        const double gxi = sample(4), gyi = sample(8);
+        double res, gxi, gyi;
+        if constexpr (REC) {
+          res = sample(w.rec[0].i(), w.rec[1].i(), w.rec[2].i(), w.rec[3].i()) - w.i0;
+          gxi = sample(w.rec[0].gx(), w.rec[1].gx(), w.rec[2].gx(), w.rec[3].gx());
+          gyi = sample(w.rec[0].gy(), w.rec[1].gy(), w.rec[2].gy(), w.rec[3].gy());
+        } else {
+          res = sample(w.tap[0], w.tap[1], w.tap[2], w.tap[3]) - w.i0;
+          gxi = sample(w.tap[4], w.tap[5], w.tap[6], w.tap[7]);
+          gyi = sample(w.tap[8], w.tap[9], w.tap[10], w.tap[11]);
+        }
 
         const double base = pz * t4 + py * t5 + px * t15;                 // (pz*temp4+py*temp5+px*temp15) = X - x
         const double Au = CORRECTED ? base + cx : base + px * cx;         // reference: px*(temp15 + x)  (:253)

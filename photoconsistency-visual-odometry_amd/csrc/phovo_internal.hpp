@@ -51,6 +51,7 @@ struct GNLevelArgs {
   const int *handover_in;
   int *handover_out;
   unsigned takeover_flag;
+  size_t rec_off;           // bilinear sampling: byte offset, in a frame, of its TAP RECORDS {I, GX, GY, pad} (pyr_build_tap_records)
 };
 
 // Several consecutive levels of one launch (gn_fused_kernel): lv[0] is the coarsest.  The pair list, states, reports and
@@ -131,6 +132,11 @@ hipError_t pyr_store_plane(const double *src, size_t src_frame_stride, int frame
                            size_t dst_frame_bytes, int storage, bool is_depth, hipStream_t stream);
 hipError_t pyr_load_plane(const unsigned char *src, int n, double *dst, int storage, bool is_depth,
                           hipStream_t stream);
+// Bilinear sampling (extension): one interleaved record {I, GX, GY, pad} per pixel of a target frame, in the planes' own
+// storage type (the same bits as the three planes), so that a bilinear tap is one or two wide loads instead of three
+// gathers: frames consecutive frames of a level pool, planes at plane_off[] and the records at rec_off in every frame.
+hipError_t pyr_build_tap_records(unsigned char *pool, size_t frame_bytes, const size_t plane_off[PLANES_PER_FRAME],
+                                 size_t rec_off, int frames, int n, int storage, hipStream_t stream);
 hipError_t pyr_gaussian_blur(double *img, double *tmp, int w, int h, int ksize,
                              const double *d_kernel, hipStream_t stream);
 hipError_t fill_i32(int *dst, size_t n, int value, hipStream_t stream);

@@ -181,6 +181,23 @@ __global__ __launch_bounds__(256) void k_load_plane(const unsigned char *src, in
   if (i < n) dst[i] = get(reinterpret_cast<const T *>(src) + i);
 }
 
+// Tap records of the bilinear extension: rec[k] = {I[k], GX[k], GY[k], 0} in the storage type T of the three planes.
+template <typename T>
+__global__ __launch_bounds__(256) void k_build_tap_records(unsigned char *pool, size_t frame_bytes, size_t off_i, size_t off_gx,
+                                                           size_t off_gy, size_t rec_off, int n)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  unsigned char *frame = pool + (size_t)blockIdx.z * frame_bytes;
+  const T *pi = reinterpret_cast<const T *>(frame + off_i), *pgx = reinterpret_cast<const T *>(frame + off_gx);
+  const T *pgy = reinterpret_cast<const T *>(frame + off_gy);
+  T *rec = reinterpret_cast<T *>(frame + rec_off) + (size_t)4 * k;
+  rec[0] = pi[k];
+  rec[1] = pgx[k];
+  rec[2] = pgy[k];
+  rec[3] = T(0);
+}
+
 inline dim3 grid3d(int w, int h, int frames)
 {
   return dim3((unsigned)((w + 255) / 256), (unsigned)h, (unsigned)frames);
@@ -245,6 +262,17 @@ hipError_t pyr_load_plane(const unsigned char *src, int n, double *dst, int stor
   if (es == 8) hipLaunchKernelGGL(k_load_plane<double>, grid, dim3(256), 0, stream, src, n, dst);
   else if (es == 4) hipLaunchKernelGGL(k_load_plane<float>, grid, dim3(256), 0, stream, src, n, dst);
   else hipLaunchKernelGGL(k_load_plane<__half>, grid, dim3(256), 0, stream, src, n, dst);
+  return hipGetLastError();
+}
+
+hipError_t pyr_build_tap_records(unsigned char *pool, size_t frame_bytes, const size_t plane_off[PLANES_PER_FRAME],
+                                 size_t rec_off, int frames, int n, int storage, hipStream_t stream)
+{
+  const dim3 grid((unsigned)((n + 255) / 256), 1, (unsigned)frames);
+  const size_t oi = plane_off[PLANE_I], ogx = plane_off[PLANE_GX], ogy = plane_off[PLANE_GY];
+  if (storage == PHOVO_STORAGE_F64) hipLaunchKernelGGL(k_build_tap_records<double>, grid, dim3(256), 0, stream, pool, frame_bytes, oi, ogx, ogy, rec_off, n);
+  else if (storage == PHOVO_STORAGE_F32) hipLaunchKernelGGL(k_build_tap_records<float>, grid, dim3(256), 0, stream, pool, frame_bytes, oi, ogx, ogy, rec_off, n);
+  else hipLaunchKernelGGL(k_build_tap_records<__half>, grid, dim3(256), 0, stream, pool, frame_bytes, oi, ogx, ogy, rec_off, n);
   return hipGetLastError();
 }
 

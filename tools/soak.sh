@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round-4 robustness session on the GPU box (through gpurun): long randomised sweeps and soaks on the round's final kernels.
-#     bash tools/soak_r04.sh gpurun_out/r4s
+# Robustness session on the GPU box (through gpurun): long randomised sweeps and soaks on the round's final kernels.
+#     bash tools/soak.sh gpurun_out/<dir>
 set -o pipefail
 O=$1
 mkdir -p $O
