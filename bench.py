@@ -165,6 +165,7 @@ def profile_context(kernel, pairs):
                         out["traffic"] = kd["hbm_bytes_per_launch"]
                         out["traffic_source"] = f"profiles/{f} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, calibrated)"
                         out["profile_library_sha256"] = doc.get("library_sha256")
+                        out["profile_source_sha256"] = doc.get("source_sha256")
                         out["profile_commit"] = doc.get("commit")
                 sq = os.path.join(prof, f.replace("_pmc_traffic.json", "_pmc_sq.json"))
                 if os.path.exists(sq):
@@ -467,12 +468,16 @@ def main():
     # `traffic` (the contract's field) is filled from it only when the profile was collected on THIS build of the library.
     stored = None
     if ctx:
-        lib_sha = library_sha256()
-        same_build = ctx.get("profile_library_sha256") == lib_sha
+        # the same BUILD: the library file the counters were collected on, or -- the file is not reproducible bit for bit across
+        # build directories -- a library built from the same sources
+        lib_sha, src_sha = library_sha256(), native.source_sha256()
+        same_build = ctx.get("profile_library_sha256") == lib_sha or (ctx.get("profile_source_sha256") is not None and
+                                                                      ctx.get("profile_source_sha256") == src_sha)
         stored = dict(note="read from committed rocprofv3 counter passes (profiles/), NOT measured in this run; the "
                            "*_with_this_runs_duration figures divide the stored bytes by this run's launch duration",
-                      library_sha256_of_profile=ctx.get("profile_library_sha256"), commit_of_profile=ctx.get("profile_commit"),
-                      library_sha256_loaded=lib_sha, same_build_as_loaded_library=bool(same_build))
+                      library_sha256_of_profile=ctx.get("profile_library_sha256"), source_sha256_of_profile=ctx.get("profile_source_sha256"),
+                      commit_of_profile=ctx.get("profile_commit"),
+                      library_sha256_loaded=lib_sha, source_sha256_of_this_tree=src_sha, same_build_as_loaded_library=bool(same_build))
         if ctx.get("traffic") is not None:
             stored["traffic"] = ctx["traffic"]
             stored["traffic_source"] = ctx["traffic_source"]

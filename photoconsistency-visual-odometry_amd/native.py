@@ -159,6 +159,22 @@ def library_path():
     return _SO
 
 
+def source_sha256():
+    """sha256 over the sources libphovo_hip.so is built from (csrc/*.hip, *.hpp, *.cpp, the Makefile, include/phovo_hip.h), in
+    name order: the stamp a rocprofv3 summary under profiles/ carries (tools/profile_round.sh) and bench.py compares with the
+    tree it runs from.  (The library file itself is not reproducible bit for bit across build directories.)"""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC))
+             if f.endswith((".hip", ".hpp", ".cpp")) or f == "Makefile"]
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "phovo_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def build(force=False):
     """Compile libphovo_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     cmd = ["make", "-s", "-C", _CSRC]

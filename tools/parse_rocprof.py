@@ -140,6 +140,9 @@ def build_stamp(src):
     f = os.path.join(src, "library.sha256")
     if os.path.exists(f):
         stamp["library_sha256"] = open(f).read().split()[0]
+    f = os.path.join(src, "source.sha256")
+    if os.path.exists(f):
+        stamp["source_sha256"] = open(f).read().split()[0]
     try:
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         stamp["commit"] = subprocess.check_output(["git", "-C", root, "rev-parse", "HEAD"], text=True).strip()

@@ -13,6 +13,7 @@ mkdir -p "$OUT"
 BENCH="python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-reference-termination --distinct 32 $*"      # (a later --distinct among the extra arguments wins)
 echo "$BENCH" > "$OUT/command.txt"
 sha256sum "$ROOT/photoconsistency-visual-odometry_amd/libphovo_hip.so" > "$OUT/library.sha256"      # which build the counters belong to
+python3 -c "import sys; sys.path.insert(0, '$ROOT'); import phovo_amd; from phovo_amd import native; print(native.source_sha256())" > "$OUT/source.sha256"      # ... and which sources
 cd /tmp
 export TMPDIR=/tmp
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/stats.log" 2>&1
