@@ -1203,7 +1203,7 @@ int phovo_engine_enqueue_align(phovo_engine *e, int n_pairs, const int *source_f
 
     if (e->ext.sampling == PHOVO_SAMPLING_BILINEAR) {
       PHOVO_HIP_CHECK(gn_launch_level_bilinear(a, e->ext.plane_storage, e->ext.jacobian_corrected != 0, e->cu_count, s.stream));
-      record(l, l, PHOVO_LAUNCH_BILINEAR, 256, 0, persistent_grid(gn_bilinear_wgs_per_cu()));
+      record(l, l, PHOVO_LAUNCH_BILINEAR, 256, 0, persistent_grid(gn_bilinear_wgs_per_cu(e->ext.plane_storage)));
     } else if (use_wide_level(e, n_pairs, lv) && !(e->ext.huber_delta[l] > 0.0)) {
       if (s.owner_tagged) {            // the wide form starts from -1 everywhere and leaves it so
         PHOVO_HIP_CHECK(fill_i32(s.d_owner, s.owner_capacity, -1, s.stream));

@@ -240,34 +240,7 @@ __device__ __forceinline__ double plane_load<__half>(__amdgpu_buffer_rsrc_t r, i
   return (double)__half2float(__ushort_as_half(bits));
 }
 
-// Elements idx and idx + 1 of a plane in ONE load (the two horizontal taps of a bilinear sample): 16 / 8 / 4 bytes.
-// Both elements must lie inside the plane.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-template <typename T>
-__device__ __forceinline__ void plane_load2(__amdgpu_buffer_rsrc_t r, int idx, double &a, double &b);
-template <>
-__device__ __forceinline__ void plane_load2<double>(__amdgpu_buffer_rsrc_t r, int idx, double &a, double &b)
-{
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, idx * 8, 0, 0);
-  a = __hiloint2double((int)v.y, (int)v.x);
-  b = __hiloint2double((int)v.w, (int)v.z);
-}
-template <>
-__device__ __forceinline__ void plane_load2<float>(__amdgpu_buffer_rsrc_t r, int idx, double &a, double &b)
-{
-  const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, idx * 4, 0, 0);
-  a = (double)__uint_as_float(v.x);
-  b = (double)__uint_as_float(v.y);
-}
-template <>
-__device__ __forceinline__ void plane_load2<__half>(__amdgpu_buffer_rsrc_t r, int idx, double &a, double &b)
-{
-  // (idx may be odd: the pair is not dword-aligned then, so two 16-bit loads -- still one fewer address computation)
-  const unsigned short lo = __builtin_amdgcn_raw_buffer_load_b16(r, idx * 2, 0, 0);
-  const unsigned short hi = __builtin_amdgcn_raw_buffer_load_b16(r, idx * 2 + 2, 0, 0);
-  a = (double)__half2float(__ushort_as_half(lo));
-  b = (double)__half2float(__ushort_as_half(hi));
-}
 
 // 1/x to within one ulp: v_rcp_f64 seeds two Newton steps.  The IEEE-exact division sequence is
 // 11 instructions, this is 5; the half-ulp it gives up is far below the fp64 noise floor of the sums

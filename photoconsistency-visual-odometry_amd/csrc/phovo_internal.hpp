@@ -97,10 +97,11 @@ bool gn_level_fusable(int n_pixels);
 int gn_fused_lds_bytes(int n_max);
 bool gn_plan_fused_geometry(int n_pixels, GNLaunchPlan *plan);      // the per-level kernel in the fused launch's geometry
 hipError_t gn_launch_fused(const GNFusedArgs &args, int storage, int cu_count, hipStream_t stream);
-// Extension (PHOVO_SAMPLING_BILINEAR): single-pass kernel, 256 threads, no owner map, any level size.
+// Extension (PHOVO_SAMPLING_BILINEAR): single-pass kernels, 256 threads, no owner map, any level size (fp64 / fp32 planes:
+// taps through LDS-DMA; fp16 planes: tap records).
 hipError_t gn_launch_level_bilinear(const GNLevelArgs &args, int storage, bool corrected, int cu_count,
                                     hipStream_t stream);
-int gn_bilinear_wgs_per_cu();      // workgroups of the bilinear kernel that stay resident per CU
+int gn_bilinear_wgs_per_cu(int storage);      // workgroups of the bilinear kernel for that plane storage that stay resident per CU
 // Wide form (gn_wide_kernels.hip): many workgroups per pair, three launches per iteration; for a handful of
 // pairs on large levels.  fp64 planes, reference semantics only.
 size_t gn_wide_workspace_bytes(int n, int n_pairs);

@@ -18,7 +18,8 @@ With `strips` every case is a one-level strip of 250-330 x 12-20 pixels (that sh
 
 With `ext` every case also draws a combination of the opt-in extensions (fp32 / fp16 plane storage, Huber weights,
 bilinear sampling with or without the corrected Jacobian); the oracle is then fed the planes as the device stored them.
-With `big` the images are 240x200 ... 700x500 with 1-2 levels, 40 or 300 pairs and in-plane rotations of up to 0.25 rad:
+PHOVO_TOOLS_LIBRARY=<path> sweeps another build of the library (e.g. csrc/build_tuning/libphovo_hip_tuning.so with its
+environment switches).  With `big` the images are 240x200 ... 700x500 with 1-2 levels, 40 or 300 pairs and in-plane rotations of up to 0.25 rad:
 level 0 then exceeds what an owner map in LDS holds, i.e. the sliding-window kernel and, for the large rotations, its
 hand-over to the exact kernel (PHOVO_PAIR_WINDOW_FALLBACK) are what is being swept.
 """
@@ -28,6 +29,9 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(sys.path[0], "tools"))
+import _variant  # noqa: E402
+_variant.use_from_environment()       # PHOVO_TOOLS_LIBRARY=<a diagnostic build>: sweep that build instead (tools/_variant.py)
 import phovo_amd  # noqa: E402,F401
 from phovo_amd import native, odometry, se3, synthetic  # noqa: E402
 from oracle import oracle  # noqa: E402
