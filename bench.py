@@ -116,8 +116,11 @@ def launch_rows(launches, per_level_ms, steps, iters, level_sizes, plane_bytes, 
         pair_it = {str(l): float(iters[:, l].sum()) for l in lv}
         nbytes = sum(plane_bytes * level_sizes[l] * pair_it[str(l)] for l in lv)
         ms = per_level_ms[lv[0]] / steps
+        name = KERNEL_NAMES[rec["kind"]]
+        if rec["kind"] == "bilinear" and not storage_types.startswith("__half"):
+            name += "_dma"              # fp64 / fp32 planes: the taps-through-LDS form (gn_bilinear_kernel.hip)
         rows.append(dict(levels=lv, pixels=[level_sizes[l] for l in lv], kind=rec["kind"],
-                         kernel=f"{KERNEL_NAMES[rec['kind']]}<{rec['threads']}, ... {storage_types}>",
+                         kernel=f"{name}<{rec['threads']}, ... {storage_types}>",
                          threads=rec["threads"], lds_bytes=rec["lds_bytes"], workgroups=rec["workgroups"],
                          avg_launch_ms=ms, pair_iterations_per_level=pair_it,
                          iterations_per_pair={k: v / n_pairs for k, v in pair_it.items()},
