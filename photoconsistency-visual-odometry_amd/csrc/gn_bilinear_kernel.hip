@@ -11,9 +11,9 @@
 //     rows: 2.5 x slower), sampler / accumulator waves (162 k fp64): profiles/r04_runs/bilinear_{lds,roles}_ab.txt;
 //   round 5, tap records: fp16 +14 % (224 k: 4 loads per pixel instead of 12), fp32 -5 %, fp64 +-0 (8 loads instead of 12
 //     changed nothing: it was never the NUMBER of gathers) -> kept for fp16;
-//   round 5, taps through LDS-DMA: fp32 240 k (+23 %), fp64 119 k with 24 dword loads per chunk (a CU has one address
-//     path: twice the instructions cost a third of the rate) and 193 k (+8 %) with the two taps of a row as ONE 16-byte
-//     load (6 per chunk) -> kept for fp64 and fp32.
+//   round 5, taps through LDS-DMA: fp32 223 k (+14 %), fp64 119 k with 24 dword loads per chunk (a CU has one address
+//     path: twice the instructions cost a third of the rate) and 187-193 k (+5...8 %) with the two taps of a row as ONE
+//     16-byte load (6 per chunk) -> kept for fp64 and fp32.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 
@@ -341,11 +341,15 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel_bilinear_dma(const GNL
     double cd = cd0, rd = rd0;
     double pz_next = plane_load<TD>(rD0, k);                              // past the plane: 0
     double i0_next = plane_load<TI>(rI0, k);
+    // (the depth and source intensity of the chunk after the one warp() has just worked on: requested by prefetch(), which the
+    // loop calls right IN FRONT of a batch of LDS-bound loads, never behind one -- see the wait in the loop)
+    auto prefetch = [&]() {
+      pz_next = plane_load<TD>(rD0, k);
+      i0_next = plane_load<TI>(rI0, k);
+    };
     auto warp = [&](Warped &w) {            // geometry of the wave's next chunk; the taps are requested by issue()
       const double pz = pz_next;
       w.i0 = i0_next;
-      pz_next = plane_load<TD>(rD0, k + NW * WAVE);
-      i0_next = plane_load<TI>(rI0, k + NW * WAVE);
       const double px = (cd - ox) * pz * ifx;                             // :282
       const double py = (rd - oy) * pz * ify;                             // :283
       const double X = ((t15 * px + r01 * py) + r02 * pz) + cx;           // :291
@@ -472,26 +476,30 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel_bilinear_dma(const GNL
       int chunk = wave;                                                   // wave-uniform loop control throughout
       if (chunk < A.n_chunks) {
         warp(w0);
+        prefetch();
         issue(w0, 0);
         for (;;) {
           chunk += NW;
           const bool more1 = chunk < A.n_chunks;
-          // The taps about to be read were requested a chunk ago; behind them only warp()'s two prefetches (depth, source
-          // intensity) have gone out.  The wait is said explicitly: the loads' destination is LDS, and what the compiler
-          // infers about a later ds_read of it is not something to rest a result on (a first version without these
-          // lines was wrong in one alignment out of five, differently from copy to copy).
-          if (more1) { warp(w1); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
-          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (more1) warp(w1);
+          // The taps about to be read were requested a chunk ago, and NOTHING has been requested since.  That is on purpose,
+          // and the wait is for everything: on gfx950 a register-bound load issued BEHIND LDS-bound ones may retire before them
+          // (tools/probes/lds_dma_probe.hip, variant 3: `s_waitcnt vmcnt(2)` with two younger register loads outstanding left
+          // the last two LDS words unwritten in 98 % of all trials), so a count that lets the youngest loads stay out is
+          // only sound when those are LDS-bound too (variant 5) or the register-bound ones are the OLDER (variant 4: that is
+          // how warp() gets its depth -- prefetch() runs in front of issue()).  The wait is explicit: what the compiler infers
+          // about a ds_read behind such loads is not something to rest a result on.
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           read_taps(0, w0, smp);
-          if (more1) issue(w1, 1);
+          if (more1) { prefetch(); issue(w1, 1); }
           consume(w0, smp);
           if (!more1) break;
           chunk += NW;
           const bool more0 = chunk < A.n_chunks;
-          if (more0) { warp(w0); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
-          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (more0) warp(w0);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           read_taps(1, w1, smp);
-          if (more0) issue(w0, 0);
+          if (more0) { prefetch(); issue(w0, 0); }
           consume(w1, smp);
           if (!more0) break;
         }
