@@ -71,25 +71,31 @@ def test_work_loop_head_is_the_barrier(kernels):
         assert waited, f"{name}: no s_waitcnt lgkmcnt(0) in front of the work loop's barrier"
 
 
-def _lds_settled_before(lines, pos, labels_at, branches_to, seen, depth=0):
+def _lds_settled_before(lines, pos, labels_at, branches_to, seen, depth=0, settles=None, offends=None, visited=None):
     """Walks back from line `pos` over EVERY path of the control-flow graph: None if each of them meets an
-    `s_waitcnt lgkmcnt(0)` before any LDS instruction, else a description of the first offender."""
+    `s_waitcnt lgkmcnt(0)` before any LDS instruction, else a description of the first offender.  (settles / offends:
+    other predicates for the same walk; visited: a set shared by the whole walk -- a block seen once on any path is either
+    settled or being judged further up, so it is not walked again and the depth is not limited.)"""
+    settles = settles or (lambda t: t.startswith("s_waitcnt") and "lgkmcnt(0)" in t)
+    offends = offends or (lambda t: t.startswith("ds_"))
     j = pos
     while j >= 0:
         t = lines[j].strip()
-        if t.startswith("s_waitcnt") and "lgkmcnt(0)" in t:
+        if settles(t):
             return None
-        if t.startswith("ds_"):
-            return f"LDS instruction '{t}' (line {j + 1}) reaches the barrier without a wait"
+        if offends(t):
+            return f"instruction '{t}' (line {j + 1}) reaches line {pos + 2} without the wait"
         if re.match(r"^_Z\w+:", t):
             return None                                    # the kernel's entry: nothing outstanding
         m = re.match(r"^(\.LBB\d+_\d+):", t)
         if m:
             label = m.group(1)
-            if label in seen:
+            if label in seen or (visited is not None and label in visited):
                 return None                                # a loop closed: its other ways in decide
             seen = seen | {label}
-            if depth > 12:
+            if visited is not None:
+                visited.add(label)
+            elif depth > 12:
                 return f"gave up at {label}"
             preds = list(branches_to.get(label, []))
             k = j - 1                                      # falls through from the block laid out in front of it?
@@ -99,7 +105,7 @@ def _lds_settled_before(lines, pos, labels_at, branches_to, seen, depth=0):
             if k >= 0 and not lines[k].strip().startswith(("s_branch", "s_endpgm", "s_setpc")):
                 preds.append(k + 1)                        # (walk starts at k)
             for q in preds:
-                bad = _lds_settled_before(lines, q - 1, labels_at, branches_to, seen, depth + 1)
+                bad = _lds_settled_before(lines, q - 1, labels_at, branches_to, seen, depth + 1, settles, offends, visited)
                 if bad:
                     return bad
             return None
@@ -210,3 +216,53 @@ def test_no_scratch_in_innermost_loops(kernels):
                 current = own if own in inner else (m.group(1) if m and m.group(1) in inner else None)
             elif current and "scratch_" in l:
                 raise AssertionError(f"{name}: scratch traffic inside innermost loop {current}: {l.strip()}")
+
+
+def test_lds_bound_loads_are_waited_for_completely_and_never_use_the_instruction_offset():
+    """gn_level_kernel_bilinear_dma lands its taps in LDS with buffer_load ... lds.  Two things tools/probes/lds_dma_probe.hip
+    measured on gfx950 are pinned in the assembly: (1) such a load carries no instruction offset (that field moves the LDS
+    address along with the memory address); (2) on EVERY path from such a load to a read of LDS there is an
+    `s_waitcnt vmcnt(0)` -- a count that lets the youngest loads stay out is unsound when register-bound loads have been
+    issued behind the LDS-bound ones (they may retire first), so the kernel waits for everything, explicitly."""
+    subprocess.run(["make", "-s", "-C", CSRC, "isa"], check=True, capture_output=True)
+    lines = open(os.path.join(CSRC, "build", "gn_bilinear_kernel.s")).read().split("\n")
+    labels_at, branches_to = {}, {}
+    for i, l in enumerate(lines):
+        t = l.strip()
+        m = re.match(r"^(\.LBB\d+_\d+):", t)
+        if m:
+            labels_at[m.group(1)] = i
+        m = re.match(r"^s_c?branch\w*\s+(\.LBB\d+_\d+)", t)
+        if m:
+            branches_to.setdefault(m.group(1), []).append(i)
+    dma = [i for i, l in enumerate(lines) if re.match(r"^buffer_load_\w+ .* lds\b", l.strip())]
+    assert len(dma) >= 4 * (6 + 12), "expected the LDS-bound tap loads of the four instantiations"       # fp64: 6 per chunk, fp32: 12
+    for i in dma:
+        assert "offset:" not in lines[i], f"line {i + 1}: an LDS-bound load with an instruction offset: {lines[i].strip()}"
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN9phovo_hip.*gn_level_kernel_bilinear_dma.*:", l)]
+    assert len(starts) == 4
+    reads = 0
+    for a in starts:
+        b = next(i for i in range(a, len(lines)) if "s_endpgm" in lines[i])
+        for i in range(a, b):
+            if not lines[i].strip().startswith("ds_read"):
+                continue
+            reads += 1
+            bad = _lds_settled_before(lines, i - 1, labels_at, branches_to, frozenset(),
+                                      settles=lambda t: t.startswith("s_waitcnt") and "vmcnt(0)" in t,
+                                      offends=lambda t: bool(re.match(r"^buffer_load_\w+ .* lds\b", t)), visited=set())
+            assert bad is None, f"gn_bilinear_kernel.s line {i + 1}: {bad}"
+    assert reads >= 4 * 12
+    # and the walk with these predicates does see a partial wait
+    listing = """
+_Zkernel:
+ buffer_load_dword v1, s[4:7], s8 offen lds
+ buffer_load_dword v2, v1, s[4:7], 0 offen
+ s_waitcnt vmcnt({n})
+ ds_read_b32 v0, v3
+""".strip().split("\n")
+    for n, ok in ((1, False), (0, True)):
+        got = _lds_settled_before([l.format(n=n) for l in listing], 3, {}, {}, frozenset(),
+                                  settles=lambda t: t.startswith("s_waitcnt") and "vmcnt(0)" in t,
+                                  offends=lambda t: bool(re.match(r"^buffer_load_\w+ .* lds\b", t)), visited=set())
+        assert (got is None) == ok
