@@ -246,6 +246,10 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel_bilinear(const GNLevel
 }
 
 
+// A wave-uniform constant read out of LDS where it is used (volatile: never hoisted into registers that the loop then carries).
+typedef const volatile __attribute__((address_space(3))) double *lds_cst_ptr;
+__device__ __forceinline__ lds_cst_ptr lds_cst(const double *p) { return (lds_cst_ptr)p; }
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // The same alignment with the taps landing in LDS instead of registers (fp64 / fp32 planes; round 5).  A form that keeps two
 // chunks' worth of taps in registers needs 252 of them, i.e. two waves per SIMD, and with two waves a SIMD has nothing to
@@ -274,7 +278,14 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel_bilinear_dma(const GNL
   const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
   const int n = A.n, W = A.w, H = A.h;
   unsigned char *const my_slots = s_taps + (size_t)wave * 2 * SLOT_BYTES;
-  if (tid == 0) s_ctl[CTL_PAIR] = draw_pair(A.work_counter, A.n_queues, A.n_pairs);
+  // (bounds the warp compares against: kept behind the pose constants in LDS, read back per chunk -- see consume())
+  enum { C_MIN_D = 24, C_MAX_D, C_WLIM, C_HLIM };
+  static_assert(C_MIN_D >= C_COUNT && C_HLIM < 32, "spare slots of the constant block");
+  if (tid == 0) {
+    s_cst[C_MIN_D] = A.min_depth; s_cst[C_MAX_D] = A.max_depth;
+    s_cst[C_WLIM] = (double)A.w - 0.5; s_cst[C_HLIM] = (double)A.h - 0.5;
+    s_ctl[CTL_PAIR] = draw_pair(A.work_counter, A.n_queues, A.n_pairs);
+  }
   for (;;) {                                // work queue, as in gn_level_kernel
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // see gn_level_kernel
   __syncthreads();
@@ -303,8 +314,6 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel_bilinear_dma(const GNL
   __syncthreads();
 
   const double fx = A.fx, fy = A.fy, ox = A.ox, oy = A.oy, ifx = A.ifx, ify = A.ify;
-  const double min_d = A.min_depth, max_d = A.max_depth;
-  const double wlim = (double)W - 0.5, hlim = (double)H - 0.5;
   const double huber_delta = A.huber_delta;
   const bool huber_on = huber_delta > 0.0;
   const int k0 = wave * WAVE + lane;
@@ -321,11 +330,7 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel_bilinear_dma(const GNL
     const double r01 = uniform_f64(s_cst[C_R01]), r02 = uniform_f64(s_cst[C_R02]);
     const double r11 = uniform_f64(s_cst[C_R11]), r12 = uniform_f64(s_cst[C_R12]);
     const double t1 = uniform_f64(s_cst[C_T1]), t2 = uniform_f64(s_cst[C_T2]), t3 = uniform_f64(s_cst[C_T3]);
-    const double t4 = uniform_f64(s_cst[C_T4]), t5 = uniform_f64(s_cst[C_T5]), t6 = uniform_f64(s_cst[C_T6]);
-    const double t8 = uniform_f64(s_cst[C_T8]), t14 = uniform_f64(s_cst[C_T14]), t15 = uniform_f64(s_cst[C_T15]);
-    const double t16 = uniform_f64(s_cst[C_T16]), t17 = uniform_f64(s_cst[C_T17]), t24 = uniform_f64(s_cst[C_T24]);
-    const double cosy = uniform_f64(s_cst[C_CY]), siny = uniform_f64(s_cst[C_SY]);
-    const double t7 = -t6, t9 = -t8, t21 = -t5;
+    const double t14 = uniform_f64(s_cst[C_T14]), t15 = uniform_f64(s_cst[C_T15]);
 
     double acc[NRED];
 #pragma unroll
@@ -334,7 +339,6 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel_bilinear_dma(const GNL
     struct Warped {
       double px, py, pz, Zr, t25, ax, ay, i0;
       int off[4];                           // byte offsets in a plane: fp32 the taps p00, p01, p10, p11; fp64 [0], [1]: the two PAIRS
-      int edge;                             // fp64: bit 0 = both taps of a row are column 0, bit 1 = both are column W - 1
       unsigned long long m;                 // lanes that are valid and land in bounds
     };
     int k = k0;
@@ -350,6 +354,8 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel_bilinear_dma(const GNL
     auto warp = [&](Warped &w) {            // geometry of the wave's next chunk; the taps are requested by issue()
       const double pz = pz_next;
       w.i0 = i0_next;
+      const double min_d = lds_cst(s_cst)[C_MIN_D], max_d = lds_cst(s_cst)[C_MAX_D];
+      const double wlim = lds_cst(s_cst)[C_WLIM], hlim = lds_cst(s_cst)[C_HLIM];
       const double px = (cd - ox) * pz * ifx;                             // :282
       const double py = (rd - oy) * pz * ify;                             // :283
       const double X = ((t15 * px + r01 * py) + r02 * pz) + cx;           // :291
@@ -364,23 +370,26 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel_bilinear_dma(const GNL
             __builtin_amdgcn_ballot_w64(tr < hlim);
       w.px = px; w.py = py; w.pz = pz; w.Zr = Zr; w.t25 = t25;
       const double fc = floor(tc), fr = floor(tr);
-      w.ax = tc - fc;
       w.ay = tr - fr;
       // (lanes outside w.m: whatever the conversions give; their taps are range-checked reads nobody uses)
       const int ic = (int)fc, ir = (int)fr;
       const int r0w = __mul24(min(max(ir, 0), H - 1), W), r1w = __mul24(min(max(ir + 1, 0), H - 1), W);
       if (PAIRS) {
         // fp64 planes: the two horizontal taps of a row are neighbours in memory and travel as ONE 16-byte load (24 dword loads
-        // per chunk made this form a third SLOWER than the gathers: a CU has one address path); in the outer half-pixel band
-        // both taps are the edge pixel: the pair is loaded one column inside and the edge value taken twice when it is read
+        // per chunk made this form a third SLOWER than the gathers: a CU has one address path).  In the outer half-pixel band
+        // both taps are the edge pixel e: the pair is loaded one column inside and the horizontal weight is set to 0 (left
+        // band: the pair is (e, x)) or 1 (right band: (x, e)), so that the row gives 1 * e + 0 * x.  That is the value of
+        // (1 - ax) * e + ax * e up to its rounding, i.e. within one ulp of the clamped-tap form the other storages and the oracle
+        // use, in that band only; selecting the taps instead cost 24 v_cndmask per chunk in a kernel whose vector units are
+        // 93 % busy (profiles/r05_bilinear_pmc_sq.json).  x is a pixel of the plane, finite whenever the plane is.
         const int cb = min(max(ic, 0), max(W - 2, 0));
         w.off[0] = (r0w + cb) * 8; w.off[1] = (r1w + cb) * 8; w.off[2] = w.off[3] = 0;
-        w.edge = W < 2 ? 1 : ((ic < 0 ? 1 : 0) | (ic > W - 2 ? 2 : 0));        // (a one-column image: both taps are that column)
+        w.ax = (ic < 0 || W < 2) ? 0.0 : (ic > W - 2 ? 1.0 : tc - fc);       // (a one-column image: both taps are that column)
       } else {
         const int c0i = min(max(ic, 0), W - 1), c1i = min(max(ic + 1, 0), W - 1);      // clamp-to-edge taps
         w.off[0] = (r0w + c0i) * (int)sizeof(TI); w.off[1] = (r0w + c1i) * (int)sizeof(TI);
         w.off[2] = (r1w + c0i) * (int)sizeof(TI); w.off[3] = (r1w + c1i) * (int)sizeof(TI);
-        w.edge = 0;
+        w.ax = tc - fc;
       }
       k += NW * WAVE;
       rowcol_advance(cd, rd, rc_step);
@@ -416,16 +425,13 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel_bilinear_dma(const GNL
       const unsigned char *base = my_slots + slot * SLOT_BYTES;
       const unsigned *words = reinterpret_cast<const unsigned *>(base) + lane;
       const double ax = w.ax, ay = w.ay;
-      const bool left = (w.edge & 1) != 0, right = (w.edge & 2) != 0;
 #pragma unroll
       for (int c = 0; c < 3; c++) {
         double p00, p01, p10, p11;
         if (PAIRS) {
           const double *row0 = reinterpret_cast<const double *>(base + (c * 2) * 1024) + 2 * lane;
           const double *row1 = reinterpret_cast<const double *>(base + (c * 2 + 1) * 1024) + 2 * lane;
-          const double a0 = row0[0], b0 = row0[1], a1 = row1[0], b1 = row1[1];
-          p00 = right ? b0 : a0; p01 = left ? a0 : b0;                   // (both taps the edge column in the outer half-pixel band)
-          p10 = right ? b1 : a1; p11 = left ? a1 : b1;
+          p00 = row0[0]; p01 = row0[1]; p10 = row1[0]; p11 = row1[1];   // (outer half-pixel band: see the weight in warp())
         } else {
           p00 = (double)__uint_as_float(words[(4 * c) * 64]); p01 = (double)__uint_as_float(words[(4 * c + 1) * 64]);
           p10 = (double)__uint_as_float(words[(4 * c + 2) * 64]); p11 = (double)__uint_as_float(words[(4 * c + 3) * 64]);
@@ -439,6 +445,14 @@ __global__ __launch_bounds__(T, WPS) void gn_level_kernel_bilinear_dma(const GNL
         const double px = w.px, py = w.py, pz = w.pz, Zr = w.Zr, t25 = w.t25;
         const double res = smp[0] - w.i0;
         const double gxi = smp[1], gyi = smp[2];
+        // The pose constants only this block uses come out of LDS each time (a broadcast read, the LDS pipe has room), not out
+        // of scalar registers: with them the kernel wanted ~30 more scalar registers than a wave has, and what the compiler
+        // then parks in lanes of a vector register comes back through v_readlane -- 30 of them per chunk, on vector units
+        // that are the kernel's bound.
+        const lds_cst_ptr vc = lds_cst(s_cst);
+        const double t4 = vc[C_T4], t5 = vc[C_T5], t6 = vc[C_T6], t8 = vc[C_T8];
+        const double t16 = vc[C_T16], t17 = vc[C_T17], t24 = vc[C_T24], cosy = vc[C_CY], siny = vc[C_SY];
+        const double t7 = -t6, t9 = -t8, t21 = -t5;
 
         const double base = pz * t4 + py * t5 + px * t15;                 // (pz*temp4+py*temp5+px*temp15) = X - x
         const double Au = CORRECTED ? base + cx : base + px * cx;         // reference: px*(temp15 + x)  (:253)

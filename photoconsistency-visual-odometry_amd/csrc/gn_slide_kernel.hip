@@ -216,33 +216,39 @@ __global__ __launch_bounds__(T, T / 256) void gn_level_kernel_slide(const GNLeve
       // intensity it points at, and the four planes.
       int k2 = wave2 * WAVE + lane, chunk2 = wave2;
       double kd2 = (double)k2 + 0.5;
-      int own_s[B2];
-      double i0_s[B2], pz_s[B2], gx_s[B2], gy_s[B2], i1_s[B2];
-      auto request = [&](const int b, const int kk) {
+      // Two sets of slots that swap roles from phase to phase (one is consumed while the other is being filled): with ONE set,
+      // refilled in place, the compiler lands the loads in fresh registers and copies them into the slot's registers on the
+      // loop's back edge -- 19 v_mov per phase, behind an s_waitcnt vmcnt(0) that ended every load's flight at the phase's end.
+      struct Slots {
+        int own[B2];
+        double i0[B2], pz[B2], gx[B2], gy[B2], i1[B2];
+      };
+      Slots set_a, set_b;
+      auto request = [&](Slots &S, const int b, const int kk) {
         const int o = s_owner[kk & (SLIDE_RING_PX - 1)];                // (lanes past the image: a slot of a band long consumed)
         s_owner[kk & (SLIDE_RING_PX - 1)] = -1;
-        own_s[b] = o;
-        pz_s[b] = plane_load<TD>(rS, kk, oD);
-        gx_s[b] = plane_load<TI>(rT, kk, oGX);                          // gradient at the SOURCE index  :346-347
-        gy_s[b] = plane_load<TI>(rT, kk, oGY);
-        i1_s[b] = plane_load<TI>(rT, kk, oI);                           // :309
-        i0_s[b] = plane_load<TI>(rS, o, oI);                            // :308 (owner -1: past the frame -> 0)
+        S.own[b] = o;
+        S.pz[b] = plane_load<TD>(rS, kk, oD);
+        S.gx[b] = plane_load<TI>(rT, kk, oGX);                          // gradient at the SOURCE index  :346-347
+        S.gy[b] = plane_load<TI>(rT, kk, oGY);
+        S.i1[b] = plane_load<TI>(rT, kk, oI);                           // :309
+        S.i0[b] = plane_load<TI>(rS, o, oI);                            // :308 (owner -1: past the frame -> 0)
       };
 #pragma unroll
-      for (int b = 0; b < B2; b++) request(b, k2 + b * STEP);
+      for (int b = 0; b < B2; b++) request(set_a, b, k2 + b * STEP);
       __syncthreads();
 
       // (three constants that meet another scalar inside one fma sit in vector registers, as in gn_kernels.hip)
       double oxv2 = oxi, oyv2 = oyi, cyv2 = cyy;
       asm volatile("" : "+v"(oxv2), "+v"(oyv2), "+v"(cyv2));
-      auto run_phases = [&](auto huber_tag) {
+      auto one_phase = [&](const Slots &cur, Slots &nxt, auto huber_tag) {
         constexpr bool HUBER = decltype(huber_tag)::value;
-        for (int s = m_run + 1; s < n_phases; s++) {                    // band s - m - 1; wave-uniform trip count
+        {
 #pragma unroll
           for (int b = 0; b < B2; b++) {
-            const int o = own_s[b];
-            const double pz = pz_s[b], gxi = gx_s[b], gyi = gy_s[b], pixel2 = i1_s[b], pixel1 = i0_s[b];
-            request(b, k2 + B2 * STEP);                                 // this slot's chunk of the next band (final: see above)
+            const int o = cur.own[b];
+            const double pz = cur.pz[b], gxi = cur.gx[b], gyi = cur.gy[b], pixel2 = cur.i1[b], pixel1 = cur.i0[b];
+            request(nxt, b, k2 + B2 * STEP);                            // this slot's chunk of the next band (final: see above)
             const unsigned long long mbits = s_mask[chunk2 & (SLIDE_MASK_RING - 1)];
             const unsigned long long mrow = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(mbits >> 32)) << 32) |
                                             (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)mbits);
@@ -292,6 +298,13 @@ __global__ __launch_bounds__(T, T / 256) void gn_level_kernel_slide(const GNLeve
             kd2 += (double)STEP;
           }
           __syncthreads();
+        }
+      };
+      auto run_phases = [&](auto huber_tag) {
+        for (int s = m_run + 1; s < n_phases; s += 2) {                 // band s - m - 1; wave-uniform trip count
+          one_phase(set_a, set_b, huber_tag);
+          if (s + 1 >= n_phases) break;
+          one_phase(set_b, set_a, huber_tag);
         }
       };
       // (two compiled copies, with and without the Huber weights, chosen outside the loop)

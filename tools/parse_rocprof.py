@@ -69,11 +69,11 @@ def sq_summary(rows, pairs):
             # the waves of a SIMD share one vector unit: the per-wave VALU share times the resident waves per SIMD is the
             # unit's busy fraction (4 for the 64- / 256- / 512- / 1024-thread level kernels and the fused kernel in a full
             # launch; 3 for the sliding-window kernel -- 768 threads, one workgroup per CU; 2 before its waves were split into
-            # two kinds -- and 2 for the bilinear kernel, which takes 252 registers)
+            # two kinds -- 2 for the bilinear kernel's record form (228 registers) and 3 for its LDS-landing form (168))
             if "gn_level_kernel_slide" in k:
                 e["waves_per_simd"] = 3 if "<768" in k else 2
             else:
-                e["waves_per_simd"] = 2 if "gn_level_kernel_bilinear" in k else 4
+                e["waves_per_simd"] = 3 if "gn_level_kernel_bilinear_dma" in k else (2 if "gn_level_kernel_bilinear" in k else 4)
             e["simd_valu_busy"] = e["waves_per_simd"] * m.get("SQ_ACTIVE_INST_VALU", 0.0) / wc
         if ns > 0 and "GRBM_GUI_ACTIVE" in m:
             e["effective_clock_GHz"] = m["GRBM_GUI_ACTIVE"] / 8.0 / ns

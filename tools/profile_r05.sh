@@ -17,6 +17,7 @@ if [ "$1" = "--parse" ]; then
   [ -d $O/prof_cfg1 ] && $P $O/prof_cfg1 profiles r05_cfg1 --pairs 512 $CAL --bench $O/bench_cfg1.json > /dev/null
   [ -d $O/prof_bilinear ] && $P $O/prof_bilinear profiles r05_bilinear $CAL --bench $O/bench_bilinear.json > /dev/null
   [ -d $O/prof_bilinear_f16 ] && $P $O/prof_bilinear_f16 profiles r05_bilinear_f16 $CAL --bench $O/bench_bilinear_f16.json > /dev/null
+  [ -d $O/prof_bilinear_f32 ] && $P $O/prof_bilinear_f32 profiles r05_bilinear_f32 $CAL --bench $O/bench_bilinear_f32.json > /dev/null
   mkdir -p profiles/r05_runs
   cp $O/bench_*.json profiles/r05_runs/ 2>/dev/null
   exit 0
@@ -43,6 +44,8 @@ else
   PROFILE_SKIP_CAL=1 bash tools/profile_round.sh $O/prof_bilinear --bilinear || exit 1
   bench bilinear_f16 --no-cpu-baseline --bilinear --storage f16
   PROFILE_SKIP_CAL=1 bash tools/profile_round.sh $O/prof_bilinear_f16 --bilinear --storage f16 || exit 1
+  bench bilinear_f32 --no-cpu-baseline --bilinear --storage f32
+  PROFILE_SKIP_CAL=1 PROFILE_SKIP_SQ=1 bash tools/profile_round.sh $O/prof_bilinear_f32 --bilinear --storage f32 || exit 1
   bench cfg5_f16 --no-cpu-baseline --workload cfg5 --pairs 2048 --storage f16 --huber 0.05
   bench cfg3 --no-cpu-baseline --workload cfg3
 fi
