@@ -13,7 +13,11 @@
 //     changed nothing: it was never the NUMBER of gathers) -> kept for fp16;
 //   round 5, taps through LDS-DMA: fp32 223 k (+14 %), fp64 119 k with 24 dword loads per chunk (a CU has one address
 //     path: twice the instructions cost a third of the rate) and 187-193 k (+5...8 %) with the two taps of a row as ONE
-//     16-byte load (6 per chunk) -> kept for fp64 and fp32.
+//     16-byte load (6 per chunk) -> kept for fp64 and fp32;
+//   round 5, that form's vector instructions (93 % busy at three waves per SIMD, a quarter of them no arithmetic): loop-only
+//     pose constants read from LDS where they are used instead of 30 v_readlane per chunk of spilled scalar registers, the
+//     outer half-pixel band as a weight of 0 or 1 instead of 24 v_cndmask per chunk: fp64 195 -> 215-218 k (+11-12 %),
+//     fp32 +-0 (bilinear_valu_ab.txt).
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 
@@ -258,7 +262,8 @@ __device__ __forceinline__ lds_cst_ptr lds_cst(const double *p) { return (lds_cs
 // (buffer_load_dword ... lds: lane l's dword lands at M0 + 4 l), so here a chunk's twelve taps are DMA-ed into a per-wave LDS
 // slot while the chunk before is consumed, and read back -- each lane its own words, no barrier -- when their turn comes:
 // the taps cost registers only while they are being interpolated, the kernel fits 168 registers and a third wave per SIMD.
-// Same per-pixel arithmetic as the gather form.
+// Same per-pixel arithmetic as the gather form, with one exception on fp64 planes: in the outer half-pixel band a row's
+// value is 1 * e + 0 * x instead of (1 - ax) * e + ax * e (e the edge pixel; see warp()), equal up to that sum's rounding.
 template <int T, int WPS, typename TI, typename TD, bool CORRECTED>
 __global__ __launch_bounds__(T, WPS) void gn_level_kernel_bilinear_dma(const GNLevelArgs A)
 {

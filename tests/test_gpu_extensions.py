@@ -200,3 +200,35 @@ def test_bilinear_handles_levels_of_any_size_and_rejects_bad_combinations():
         assert ei.value.status == 7
     assert list(reps[0].iterations[:1]) == eits
     assert se3.state_distance(s[0], es) < POSE_TOL
+
+
+@pytest.mark.parametrize("storage", [native.STORAGE_F64, native.STORAGE_F32, native.STORAGE_F16])
+@pytest.mark.parametrize("side", [-1.0, 1.0])
+def test_bilinear_taps_in_the_outer_half_pixel_band(storage, side):
+    """Pixels whose warped column lies in (-1/2, 0) or [W - 1, W - 1/2) take the edge pixel for both taps of a row.  The three
+    storages do that in three ways (fp64: a 16-byte pair loaded one column inside with the row's weight set to 0 or 1; fp32:
+    clamped tap addresses; fp16: the tap record of the edge pixel): the initial state shifts the whole image by a third of
+    a pixel to one side, so every row has a pixel in that band, on a small image where the band is 1 / 72 of all pixels."""
+    w, h = 72, 56
+    p = synthetic.make_pair(31, w, h, holes=0.0, trans=0.002, rot=0.001)
+    ncfg = native.make_config(num_levels=2, max_iter=[4, 4], min_grad=[0.0, 0.0])
+    ocfg = oracle.make_config(num_levels=2, max_iter=[4, 4], min_grad=[0.0, 0.0])
+    z = p["depth0"][p["depth0"] > 0]
+    tx = side * 0.3 * float(np.median(z)) / p["K"][0, 0]
+    init = np.array([tx, 0.0, 0.0, 0.0, 0.0, 0.0])
+    shift = p["K"][0, 0] * tx / z
+    assert np.mean((np.abs(shift) > 0.05) & (np.abs(shift) < 0.5)) > 0.9     # the edge column of nearly every row is in the band
+    with odometry.AlignmentEngine() as eng:
+        eng.set_config(ncfg)
+        eng.set_extensions(native.make_extensions(plane_storage=storage, sampling=native.SAMPLING_BILINEAR,
+                                                  jacobian_corrected=True))
+        eng.set_intrinsic_matrix(p["K"])
+        eng.reserve_frames(2, w, h)
+        eng.upload_frame(0, p["gray0"], p["depth0"])
+        eng.upload_frame(1, p["gray1"], p["depth1"])
+        planes = _stored_planes(eng, 0, 1, 2, [4, 4], w, h)
+        s, reps = eng.align_pairs([0], [1], init_states=init[None, :], want_reports=True)
+        assert [r["kind"] for r in eng.last_launches()] == ["bilinear"] * 2
+    es, eits = oracle.optimize(ocfg, p["K"], *planes, init_state=init, bilinear=True, corrected=True)
+    assert list(reps[0].iterations[:2]) == eits
+    assert se3.state_distance(s[0], es) < POSE_TOL
