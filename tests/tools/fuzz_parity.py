@@ -1,7 +1,8 @@
 """Randomised device-vs-oracle sweep (run on the GPU box): odd image sizes, 1-3 levels, intrinsics that are not
 half-integers, depth holes / NaN / out-of-range depth, large motions, non-zero initial states, every launch geometry
 the sizes select, optionally narrow storage / Huber / bilinear.  Prints one line per failure and a summary; exit code 1
-if any case misses the pose bar or an iteration count.
+if any case misses the pose bar or an iteration count.  A case beyond the bar whose oracle result itself moves by more than a
+quarter of that distance under one ulp of fx is reported as chaotic instead (a diverging alignment: round 5, seed 91 case 382).
 
 The pose bar is 1e-9 x max(1, cond(J^T J) / 1e5), with cond the largest condition number of the normal equations over the
 oracle's iterations (printed with every failure and, as a maximum, in the summary).  Device and oracle sum the same terms
@@ -44,6 +45,7 @@ strips = "strips" in sys.argv[3:]
 bad, worst, variants, fallbacks = 0, 0.0, {}, 0
 worst_ratio, worst_cond, ill = 0.0, 0.0, 0
 worst_ill, ill_only_by_scaling = 0.0, 0
+chaotic = 0
 
 
 def worst_condition(trace):
@@ -98,7 +100,8 @@ for case in range(cases):
                 [rs.choice([0.0, 0.02, 0.1]) for _ in range(nl)]
             if rs.rand() < 0.5:
                 rs.rand()
-        rs.choice([40, 300] if big else [1, 3, 40])
+        if int(rs.choice([40, 300] if big else [1, 3, 40])) <= 8:
+            rs.rand()                       # (the latency-forms draw of a small batch)
         continue
     if with_ext:
         storage = [native.STORAGE_F64, native.STORAGE_F32, native.STORAGE_F16][int(rs.randint(0, 3))]
@@ -160,6 +163,24 @@ for case in range(cases):
         d = 0.0
         ok = bool(reps[0].flags & native.PAIR_NONFINITE) and not np.all(np.isfinite(s[0]))
     worst = max(worst, d)
+    if not ok and finite and its == eits and d < 1e-5 and all(np.array_equal(s[0], s[i]) for i in range(n_pairs)):
+        # Missed the scaled bar with equal iteration counts: before calling it a failure, ask the ORACLE how far its own result
+        # moves when one focal length changes by one ulp.  An alignment that is diverging (a strip with a 0.05 rad rotation
+        # ends at x = 5.7 m, pitch -3.2 rad) amplifies any rounding by more than cond(J^T J) says, and no comparison can be
+        # tighter than that; such a case is counted as chaotic (and printed), not as a failure, when the device is within 4 x
+        # that one-ulp sensitivity.
+        K1 = K.copy()
+        K1[0, 0] = np.nextafter(K1[0, 0], 10.0 * K1[0, 0])
+        if with_ext:
+            es1, _ = oracle.optimize(ocfg, K1, *planes, init_state=init, huber_delta=huber, bilinear=bilinear, corrected=corrected)
+        else:
+            es1, _ = oracle.align_frames(ocfg, K1, p["gray0"], d0, p["gray1"], init_state=init)
+        sens = se3.state_distance(es, es1) if np.all(np.isfinite(es1)) else float("inf")
+        if d <= 4.0 * sens:
+            chaotic += 1
+            ok = True
+            print(f"chaotic case {case}: {w}x{h} levels {nl} max_iter {max_iter} distance {d:.3e} bar {bar:.1e} cond {cond:.2e}; "
+                  f"one ulp in fx moves the oracle's own result by {sens:.3e}")
     if not ok:
         bad += 1
         print(f"FAIL case {case}: {w}x{h} levels {nl} max_iter {max_iter} min_grad {min_grad} pairs {n_pairs} "
@@ -171,6 +192,7 @@ print(f"{cases} cases, {bad} failures, worst pose distance {worst:.3e}")
 print(f"largest cond(J^T J) {worst_cond:.2e}; {ill} cases above 1e5 (bar scaled, capped at 1e-5): worst absolute distance among them "
       f"{worst_ill:.3e}, {ill_only_by_scaling} of them passed only because of the scaling (distance >= 1e-9); "
       f"worst distance / bar {worst_ratio:.3f}")
+print(f"chaotic cases (beyond the scaled bar, within 4 x the oracle's own sensitivity to one ulp of fx; not failures): {chaotic}")
 print(f"pairs finished by the exact kernel after leaving the sliding window: {fallbacks} cases")
 print("launch geometries exercised (threads, owner in LDS, source in LDS, wide form): ", variants)
 sys.exit(1 if bad else 0)
