@@ -74,6 +74,9 @@ def sq_summary(rows, pairs):
                 e["waves_per_simd"] = 3 if "<768" in k else 2
             else:
                 e["waves_per_simd"] = 3 if "gn_level_kernel_bilinear_dma" in k else (2 if "gn_level_kernel_bilinear" in k else 4)
+            if "gn_level_kernel<64," in k and pairs:
+                # one wave per pair, 16 per CU: a launch of fewer than 4096 pairs leaves SIMDs with fewer than four waves
+                e["waves_per_simd"] = min(4.0, pairs / 1024.0)
             e["simd_valu_busy"] = e["waves_per_simd"] * m.get("SQ_ACTIVE_INST_VALU", 0.0) / wc
         if ns > 0 and "GRBM_GUI_ACTIVE" in m:
             e["effective_clock_GHz"] = m["GRBM_GUI_ACTIVE"] / 8.0 / ns
@@ -143,10 +146,17 @@ def build_stamp(src):
     f = os.path.join(src, "source.sha256")
     if os.path.exists(f):
         stamp["source_sha256"] = open(f).read().split()[0]
+    # the commit the tree stood at when the raw data was FIRST summarised is kept beside the raw data, so that summarising
+    # it again later (a fix in this parser) does not move the stamp to a commit the counters were not collected on
+    kept = os.path.join(src, "commit.json")
+    if os.path.exists(kept):
+        stamp.update(json.load(open(kept)))
+        return stamp
     try:
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         stamp["commit"] = subprocess.check_output(["git", "-C", root, "rev-parse", "HEAD"], text=True).strip()
         stamp["tree_dirty"] = bool(subprocess.check_output(["git", "-C", root, "status", "--porcelain", "--", "photoconsistency-visual-odometry_amd/csrc", "include"], text=True).strip())
+        json.dump(dict(commit=stamp["commit"], tree_dirty=stamp["tree_dirty"]), open(kept, "w"))
     except Exception:
         pass
     return stamp
