@@ -232,3 +232,35 @@ def test_bilinear_taps_in_the_outer_half_pixel_band(storage, side):
     es, eits = oracle.optimize(ocfg, p["K"], *planes, init_state=init, bilinear=True, corrected=True)
     assert list(reps[0].iterations[:2]) == eits
     assert se3.state_distance(s[0], es) < POSE_TOL
+
+
+@pytest.mark.parametrize("storage", [native.STORAGE_F64, native.STORAGE_F32, native.STORAGE_F16])
+@pytest.mark.parametrize("w,h", [(1, 40), (2, 40), (3, 37), (40, 1), (40, 2), (5, 5)])
+def test_bilinear_on_images_a_few_pixels_wide(storage, w, h):
+    """One- to three-column (and -row) images: every tap is an edge tap, the fp64 form's 16-byte pair does not fit a one-column
+    row at all (both taps are that column; the pair is loaded at column 0 and weighted 1 : 0).  Such normal equations are rank
+    deficient more often than not: then both sides must say so (non-finite state, PAIR_NONFINITE) instead of agreeing on
+    numbers."""
+    p = synthetic.make_pair(33, max(w, 8), max(h, 8), holes=0.0, trans=0.002, rot=0.001)
+    g0, d0, g1 = p["gray0"][:h, :w].copy(), p["depth0"][:h, :w].copy(), p["gray1"][:h, :w].copy()
+    K = synthetic.intrinsics(w, h)
+    ncfg = native.make_config(num_levels=1, max_iter=[3], min_grad=[0.0])
+    ocfg = oracle.make_config(num_levels=1, max_iter=[3], min_grad=[0.0])
+    with odometry.AlignmentEngine() as eng:
+        eng.set_config(ncfg)
+        eng.set_extensions(native.make_extensions(plane_storage=storage, sampling=native.SAMPLING_BILINEAR,
+                                                  jacobian_corrected=True))
+        eng.set_intrinsic_matrix(K)
+        eng.reserve_frames(2, w, h)
+        eng.upload_frame(0, g0, d0)
+        eng.upload_frame(1, g1, d0)
+        planes = _stored_planes(eng, 0, 1, 1, [3], w, h)
+        s, reps = eng.align_pairs([0, 0, 0], [1, 1, 1], want_reports=True)
+    es, eits = oracle.optimize(ocfg, K, *planes, bilinear=True, corrected=True)
+    assert np.array_equal(s[0], s[1], equal_nan=True) and np.array_equal(s[0], s[2], equal_nan=True)
+    if np.all(np.isfinite(es)):
+        assert list(reps[0].iterations[:1]) == eits
+        # (a handful of pixels: the normal equations are as ill-conditioned as they come; the bar scales as in tests/tools/fuzz_parity.py)
+        assert se3.state_distance(s[0], es) < 1e-5
+    else:
+        assert reps[0].flags & native.PAIR_NONFINITE and not np.all(np.isfinite(s[0]))
